@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory from the REFERENCE modules.
+
+Runs only in the build container (needs /root/reference); the resulting ``*.npz`` files are
+data (inputs, expected outputs, gradient digests) and are committed.  No reference source is
+copied: the modules are imported by path and executed on CPU.  Weights are not stored —
+both sides regenerate them with ``vae_gan_amd.testing.fill_state_dict`` from key names.
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py vq_step    # one group
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from vae_gan_amd.testing import (fill_state_dict, synthetic_images, synthetic_eps,  # noqa: E402
+                                 cotangent, digest)
+
+REF = os.environ.get("VG_REFERENCE", "/root/reference")
+
+
+def load_ref(sub, name):
+    spec = importlib.util.spec_from_file_location(f"ref_{sub}_{name}", os.path.join(REF, sub, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def filled(module, salt=0):
+    module.load_state_dict(fill_state_dict(module.state_dict(), salt=salt))
+    return module
+
+
+def grads_digest(module, prefix=""):
+    out = {}
+    for k, p in module.named_parameters():
+        if p.grad is not None:
+            out["gd:" + prefix + k] = digest(prefix + k, p.grad)
+    return out
+
+
+def bn_buffers(module, prefix=""):
+    out = {}
+    for k, b in module.named_buffers():
+        out["buf:" + prefix + k] = b.detach().clone().numpy()
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print(f"wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ----------------------------------------------------------------------------------------
+def g_vq_quantizer():
+    m = load_ref("vq_vae_gan", "model")
+    for tag, K, D, shape, init in [("a", 512, 64, (2, 64, 8, 8), "normal"),
+                                   ("b", 512, 64, (2, 64, 8, 8), "default"),
+                                   ("c", 8192, 256, (1, 256, 8, 8), "normal")]:
+        vq = m.VectorQuantizer(K, D, 0.25, 0.99)
+        sd = fill_state_dict(vq.state_dict())
+        if init == "default":  # reference default: U(-1/K, 1/K), ema_w = copy, cluster sizes 0
+            g = torch.Generator().manual_seed(5)
+            sd["embeddings.weight"] = (torch.rand(K, D, generator=g) * 2 - 1) / K
+            sd["ema_w"] = sd["embeddings.weight"].clone()
+            sd["ema_cluster_size"] = torch.zeros(K)
+        vq.load_state_dict(sd)
+        scale = 0.5 if init == "normal" else 1.0 / K
+        z = (synthetic_eps(shape, 100 + ord(tag)) * scale).requires_grad_(True)
+        cot = cotangent("vq:" + tag, shape)
+        zq, loss, idx = vq(z, training=True)
+        ((zq * cot).sum() + loss).backward()
+        extra = {}
+        if init == "default":   # not reproducible from key names: store the starting state
+            extra = dict(codebook_before=sd["embeddings.weight"], ema_cluster_before=sd["ema_cluster_size"],
+                         ema_w_before=sd["ema_w"])
+        if K * D > 100000:      # big codebook: digests only (fixtures stay small)
+            after = {"gd:ema_w": digest("ema_w", vq.ema_w), "gd:codebook_after": digest("codebook_after", vq.embeddings.weight)}
+        else:
+            after = dict(ema_w=vq.ema_w, codebook_after=vq.embeddings.weight)
+        save("vq_quantizer_" + tag, z=z, cot=cot, zq=zq, vq_loss=loss, idx=idx, dz=z.grad,
+             ema_cluster_size=vq.ema_cluster_size, **after, **extra)
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def _fwd_bwd_once(name, mod, x, dtype):
+    mod = mod.to(dtype).train()
+    x = x.detach().clone().to(dtype).requires_grad_(True)
+    y = mod(x)
+    ys = y if isinstance(y, (tuple, list)) else [y]
+    flat = []
+    for t in ys:
+        flat.extend(t if isinstance(t, (tuple, list)) else [t])
+    cots = [cotangent(f"{name}:{i}", t.shape).to(dtype) for i, t in enumerate(flat)]
+    sum((t * c).sum() for t, c in zip(flat, cots)).backward()
+    grads = {k: p.grad.detach().clone() for k, p in mod.named_parameters() if p.grad is not None}
+    bufs = {k: b.detach().clone() for k, b in mod.named_buffers()}
+    return [t.detach() for t in flat], cots, x.grad.detach(), grads, bufs
+
+
+def _module_fwd_bwd(name, make_mod, x, prefix):
+    """Golden = the reference module run in float64 (stored rounded to fp32: the 'truth'),
+    plus 'noise:*' = relative L2 distance of the reference's own fp32 run from that truth.
+    A piecewise-linear net has LeakyReLU sign flips under fp32 rounding, so some gradients
+    are only reproducible to that noise floor (e.g. vq_decoder dx: 9e-3), not to 1e-4."""
+    y64, cots, dx64, g64, b64 = _fwd_bwd_once(name, make_mod(), x, torch.float64)
+    y32, _, dx32, g32, b32 = _fwd_bwd_once(name, make_mod(), x, torch.float32)
+    out = {"x": x, "dx": dx64.float(), "noise:dx": rel_l2(dx32, dx64)}
+    for i, (a, b) in enumerate(zip(y32, y64)):
+        out[f"y{i}"] = b.float()
+        out[f"cot{i}"] = cots[i].float()
+        out[f"noise:y{i}"] = rel_l2(a, b)
+    for k in g64:
+        out["gd:" + prefix + k] = digest(prefix + k, g64[k])
+        out["noise:gd:" + prefix + k] = rel_l2(g32[k], g64[k])
+    for k in b64:
+        out["buf:" + prefix + k] = b64[k].float() if b64[k].dtype.is_floating_point else b64[k]
+    save(name, **out)
+
+
+def g_resblock():
+    m = load_ref("vq_vae_gan", "model")
+    _module_fwd_bwd("resblock64", lambda: filled(m.ResidualBlock(64, 64)), synthetic_eps((2, 64, 16, 16), 7), "")
+
+
+def g_vq_modules():
+    m = load_ref("vq_vae_gan", "model")
+    img = synthetic_images(2, 64, seed=42)
+    _module_fwd_bwd("vq_encoder", lambda: filled(m.Encoder(3, [64, 128, 256, 512], 64)), img, "")
+    _module_fwd_bwd("vq_decoder", lambda: filled(m.Decoder(64, [512, 256, 128, 64], 3)),
+                    0.5 * synthetic_eps((2, 64, 8, 8), 11), "")
+    _module_fwd_bwd("vq_discriminator", lambda: filled(m.Discriminator(3, [64, 128, 256, 512])), img, "")
+
+
+def _ref_vq_step(model, images, opt_g, opt_d):
+    """Re-composition of vq_vae_gan/main.py:75-111 around the reference model object."""
+    opt_d.zero_grad()
+    recon, _, _, vq_loss, idx1 = model(images)
+    d_real = model.discriminator(images)
+    d_fake = model.discriminator(recon.detach())
+    dl = model.loss_function(images, recon, vq_loss, d_real, d_fake, train_generator=False)
+    dl["total"].backward()
+    opt_d.step()
+    opt_g.zero_grad()
+    recon, _, _, vq_loss, idx2 = model(images)
+    d_fake = model.discriminator(recon)
+    gl = model.loss_function(images, recon, vq_loss, d_real, d_fake, train_generator=True)
+    gl["total"].backward()
+    opt_g.step()
+    return dl, gl, idx1, idx2, recon
+
+
+def _vq_step_run(dtype, iters=2):
+    m = load_ref("vq_vae_gan", "model")
+    cfg = load_ref("vq_vae_gan", "config").Config()
+    model = filled(m.VQVAEGAN(cfg)).to(dtype).train()
+    opt_g = torch.optim.Adam(list(model.encoder.parameters()) + list(model.decoder.parameters()),
+                             lr=cfg.lr, betas=(cfg.beta1, cfg.beta2))
+    opt_d = torch.optim.Adam(model.discriminator.parameters(), lr=cfg.lr / 2, betas=(cfg.beta1, cfg.beta2))
+    images = synthetic_images(2, 64, seed=42).to(dtype)
+    out = {"images": images.float()}
+    for it in range(iters):
+        dl, gl, idx1, idx2, recon = _ref_vq_step(model, images, opt_g, opt_d)
+        out.update({f"it{it}_d_loss": dl["total"].item(), f"it{it}_d_recon": dl["recon"],
+                    f"it{it}_g_loss": gl["total"].item(), f"it{it}_recon": gl["recon"],
+                    f"it{it}_vq": gl["vq"], f"it{it}_adv": gl["adv"],
+                    f"it{it}_idx1": idx1, f"it{it}_idx2": idx2, f"it{it}_recon_img": recon.detach().clone().float()})
+    return out, model.state_dict()
+
+
+def g_vq_step():
+    """Two iterations of the reference step in fp32 (the golden) and in fp64 (to record how far
+    the reference's own fp32 run is from exact arithmetic: 'noise:*').  Adam's first step is
+    lr*sign(g), so parameters whose gradient is rounding noise move by +-lr in a direction that
+    depends on summation order; scalars downstream are reproducible only to that floor."""
+    out, sd = _vq_step_run(torch.float32)
+    out64, _ = _vq_step_run(torch.float64)
+    for k, v in list(out.items()):
+        if k.startswith("it") and not k.endswith(("idx1", "idx2", "recon_img")):
+            out["noise:" + k] = abs(v - out64[k]) / max(abs(out64[k]), 1e-12)
+        if k.endswith(("idx1", "idx2")):
+            out["idxeq64:" + k] = float((v == out64[k]).float().mean())
+        if k.endswith("recon_img"):
+            out["noise:" + k] = rel_l2(v, out64[k])
+    for k, v in sd.items():
+        if v.dtype == torch.int64 or k.startswith("vector_quantizer"):
+            out["sd:" + k] = v.clone()
+        else:
+            out["sdd:" + k] = digest(k, v)
+    save("vq_step_64", **out)
+    print({k: v for k, v in out.items() if k.startswith(("noise:", "idxeq64"))})
+
+
+def g_losses():
+    mu = synthetic_eps((4, 128), 21)
+    lv = torch.clamp(2.0 * synthetic_eps((4, 128), 22), -20, 20)
+    eps = synthetic_eps((4, 128), 23)
+    mb = load_ref("beta_vae_gans", "model")
+
+    class C:  # minimal config object for the constructor (beta_vae_gans/config.py names)
+        latent_dim = 128; beta = 4.0; channels = 3
+        enc_channels = [8, 8]; dec_channels = [8, 8]; lambda_adv = 0.1
+    # reparameterize draws randn_like internally: reproduce by seeding and recording the draw
+    torch.manual_seed(1234)
+    eps_drawn = torch.randn_like(mu)
+    torch.manual_seed(1234)
+    z = mb.BetaVAEGAN.reparameterize(None, mu, lv)
+    d_real = synthetic_eps((2, 1, 15, 15), 24)
+    d_fake = synthetic_eps((2, 1, 7, 7), 25)
+    kl = -0.5 * torch.mean(1 + lv - mu.pow(2) - lv.exp())           # beta model.py:258 evaluated
+    hinge = torch.mean(F.relu(1.0 - d_real)) + torch.mean(F.relu(1.0 + d_fake))
+    adv = -torch.mean(d_fake)
+    save("losses", mu=mu, logvar=lv, eps=eps_drawn, z=z, d_real=d_real, d_fake=d_fake, kl=kl, hinge=hinge, adv=adv)
+
+
+def g_beta_modules():
+    m = load_ref("beta_vae_gans", "model")
+    img = synthetic_images(2, 256, seed=43)
+    _module_fwd_bwd("beta_encoder", lambda: filled(m.Encoder(3, [64, 128, 256, 512], 128)), img, "")
+    _module_fwd_bwd("beta_decoder", lambda: filled(m.Decoder(128, [512, 256, 128, 64], 3)), synthetic_eps((2, 128), 31), "")
+    _module_fwd_bwd("beta_discriminator_128", lambda: filled(m.Discriminator(3, [64, 128, 256, 512])),
+                    synthetic_images(2, 128, seed=44), "")
+
+
+def g_hier_modules():
+    m = load_ref("hierarchical_vae_gan", "model")
+    _module_fwd_bwd("hier_attention128", lambda: filled(m.SelfAttention(128)), synthetic_eps((2, 128, 16, 16), 51), "")
+    _module_fwd_bwd("hier_attention256", lambda: filled(m.SelfAttention(256)), synthetic_eps((1, 256, 8, 8), 52), "")
+    img = synthetic_images(2, 64, seed=45)
+    _module_fwd_bwd("hier_encoder", lambda: filled(m.HierarchicalEncoder(3, 64, [32, 64, 128], 3)), img, "")
+    _module_fwd_bwd("hier_discriminator", lambda: filled(m.Discriminator(3, 64, 3)), img, "")
+    dec = lambda: filled(m.HierarchicalDecoder(3, 64, [32, 64, 128], 3))
+    _module_fwd_bwd("hier_dec_block0", lambda: dec().decoders[0], 0.5 * synthetic_eps((2, 128, 8, 8), 53), "decoders.0.")
+    _module_fwd_bwd("hier_dec_block1", lambda: dec().decoders[1], 0.5 * synthetic_eps((2, 320, 16, 16), 54), "decoders.1.")
+    _module_fwd_bwd("hier_dec_block2", lambda: dec().decoders[2], 0.5 * synthetic_eps((2, 160, 32, 32), 55), "decoders.2.")
+    _module_fwd_bwd("hier_output_conv", lambda: dec().output_conv, 0.5 * synthetic_eps((2, 64, 32, 32), 56), "output_conv.")
+
+
+GROUPS = {"vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
+          "vq_step": g_vq_step, "losses": g_losses, "beta_modules": g_beta_modules,
+          "hier_modules": g_hier_modules}
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for name in (sys.argv[1:] or list(GROUPS)):
+        GROUPS[name]()
