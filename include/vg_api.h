@@ -1,0 +1,160 @@
+/* vg_api.h — C ABI of libvg_hip.so, the MI355X (gfx950) kernel library behind the VAE-GAN
+ * training step.
+ *
+ * The reference (adnanemagourt/vae-gan) has no FFI of its own: its hot path is the PyTorch op
+ * stream issued by <arch>/model.py and <arch>/main.py:68-111.  Each entry point below therefore cites the
+ * reference lines whose arithmetic it replaces.  Conventions:
+ *   - plain pointers + sizes only; every buffer (incl. workspaces) is caller-owned device memory;
+ *   - all work is enqueued on the hipStream_t passed as `void* stream`; no hidden syncs;
+ *   - return 0 on success, <0 on error; message via vg_last_error() (thread-local);
+ *   - activations are NHWC with a padded channel stride (`cs`, multiple of 32 for bf16 / 16 for
+ *     f32); `dtype` selects the storage/arithmetic type of activations and packed weights
+ *     (VG_BF16: bf16 storage + bf16 MFMA with f32 accumulate; VG_F32: f32 storage + f32 MFMA).
+ *     Master weights, gradients, statistics and optimizer state are always f32.
+ */
+#ifndef VG_API_H
+#define VG_API_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VG_F32 = 0, VG_BF16 = 1 };
+enum { VG_OK = 0, VG_ERR_BAD_ARG = -1, VG_ERR_HIP = -2, VG_ERR_UNSUPPORTED = -3 };
+enum { VG_ACT_NONE = 0, VG_ACT_LRELU = 1, VG_ACT_SIGMOID = 2 };
+
+#define VG_STATS_REPLICAS 32 /* per-channel f64 accumulators are spread over this many copies */
+
+const char* vg_last_error(void);
+int vg_version(void);
+
+/* Geometry of one convolution "weight object" W[O][I][R][S] with stride s, padding p, as
+ * nn.Conv2d(I, O, R, stride=s, padding=p) sees it.  nn.ConvTranspose2d(I_t, O_t, R, s, p) is the
+ * same object with O = I_t, I = O_t and forward/dgrad swapped. */
+typedef struct {
+  int n, h, w;        /* batch and spatial size of the conv INPUT (x)            */
+  int oh, ow;         /* spatial size of the conv OUTPUT (y)                     */
+  int ci, co;         /* logical channel counts I and O                          */
+  int xcs, ycs;       /* channel strides (padded) of the x-side / y-side tensors */
+  int r, s;           /* kernel height/width                                     */
+  int stride, pad;
+  int dtype;          /* VG_F32 | VG_BF16                                        */
+} vg_conv_desc;
+
+/* ---- weight packing ---------------------------------------------------------------------- */
+/* Bytes of the packed forward (transposed=0) or dgrad (transposed=1) weight image. */
+size_t vg_conv_packed_bytes(const vg_conv_desc* d, int transposed);
+/* OIHW f32 master weight -> packed [phase][Npad][tap][Cpad] image in `dtype`, zero padded.
+ * Replaces the implicit weight layout handling inside torch's conv (e.g. vq_vae_gan/model.py:146). */
+int vg_conv_pack_weight(const vg_conv_desc* d, int transposed, const float* w_oihw, void* packed, void* stream);
+
+/* ---- the three conv primitives ----------------------------------------------------------- */
+/* y = act(conv(x, W) + bias) [+ y if accumulate].  `stats` (optional): f64 [VG_STATS_REPLICAS][2][Npad]
+ * zeroed by the caller; receives per-channel sum / sum of squares of the (dtype-rounded) pre-activation
+ * output, for the BatchNorm that follows.  Replaces nn.Conv2d forward (beta_vae_gans/model.py:52,59;
+ * vq_vae_gan/model.py:146,153,161,179,193,211,216,221; hierarchical_vae_gan/model.py:96,116,135,...)
+ * and nn.ConvTranspose2d's input-gradient. */
+int vg_conv_fwd(const vg_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                double* stats, int act, int accumulate, void* stream);
+/* dx = act(convT(dy, W) + bias) [+ dx]: the conv's input gradient, and nn.ConvTranspose2d's forward
+ * (vq_vae_gan/model.py:186; beta_vae_gans/model.py:123).  w_packed is the transposed image. */
+int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
+                  double* stats, int act, int accumulate, void* stream);
+/* dW[O][I][R][S] (f32, OIHW) = sum over pixels of dy ⊗ im2col(x).  `ws` is f32 scratch of
+ * vg_conv_wgrad_ws_bytes(d) bytes.  Serves both Conv2d.weight.grad and ConvTranspose2d.weight.grad
+ * (roles of x / dy swapped by the caller). */
+size_t vg_conv_wgrad_ws_bytes(const vg_conv_desc* d);
+int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, void* stream);
+
+/* per-channel column sum: out[c] (f32) = sum_m a[m][c], c < c_valid.  bias gradients. */
+int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws, void* stream);
+
+/* ---- layout ------------------------------------------------------------------------------ */
+/* NCHW f32 [n][c][h][w]  <->  NHWC `dtype` [n][h][w][cs] (channels >= c written as zero). */
+int vg_nchw_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int cs, int dtype, void* stream);
+int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h, int w, int cs, int dtype, void* stream);
+
+/* ---- BatchNorm (training mode) + LeakyReLU(0.2) + residual ---------------------------------- */
+/* From the f64 stats of vg_conv_fwd: mean/invstd (biased var, eps), affine scale/shift, and the
+ * running-stat update with momentum (unbiased var) + num_batches_tracked += 1.
+ * nn.BatchNorm2d training forward (every <arch>/model.py; e.g. vq_vae_gan/model.py:18-19,147,154). */
+int vg_bn_finalize(const double* stats, int c, int cpad, int64_t count, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* y = act(x*scale[c] + shift[c] (+ res)); act per VG_ACT_*.  x,res,y: [rows][cs] `dtype`. */
+int vg_bn_act_fwd(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
+                  int cs, int c, int act, int dtype, void* stream);
+/* Backward, pass 1: sums[rep][2][cpad] (f64, zeroed) += {sum dz, sum dz*xhat} with
+ * dz = dout * (y > 0 ? 1 : 0.2) (act=LRELU) and xhat = (x-mean)*invstd. */
+int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+                     double* sums, int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream);
+/* Backward, pass 2: dx = gamma*invstd*(dz - sum_dz/n - xhat*sum_dzxhat/n); dres = dz (optional);
+ * dgamma = sum_dzxhat, dbeta = sum_dz (f32 [c]). */
+int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+                    const float* gamma, const double* sums, void* dx, void* dres, float* dgamma, float* dbeta,
+                    int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream);
+/* Plain elementwise activation backward (no BN): dx = dout * act'(y). */
+int vg_act_bwd(const void* dout, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
+/* a += b (elementwise, `dtype`): gradient fan-in of the residual skip. */
+int vg_add_inplace(void* a, const void* b, int64_t n, int dtype, void* stream);
+
+/* ---- Vector quantiser (vq_vae_gan/model.py:68-134) ---------------------------------------- */
+/* idx[i] = argmin_k (|z_i|^2 + |E_k|^2) - 2 z_i.E_k   in f32, that op order, first-min ties
+ * (model.py:88-95).  z: [rows][d] f32 row-major (NHWC flat), codebook [k][d] f32. */
+int vg_vq_assign(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx, void* stream);
+/* zq = z + (E[idx] - z); sse += sum (E[idx]-z)^2 (f64 scalar, zeroed by caller); optional EMA
+ * statistics counts[k] (f32) and esum[k][d] (f32), zeroed by caller (model.py:98-119). */
+int vg_vq_gather(const float* z, const float* codebook, const int64_t* idx, int64_t rows, int k, int d, float* zq,
+                 double* sse, float* counts, float* esum, void* stream);
+/* EMA + renormalise (model.py:114-129): cluster = cluster*decay + (1-decay)*counts; ema_w likewise;
+ * codebook = ema_w / ((cluster+1e-5)/(n+k*1e-5)*n). */
+int vg_vq_ema_update(float* ema_cluster, float* ema_w, float* codebook, const float* counts, const float* esum,
+                     int k, int d, float decay, void* stream);
+/* dz = g_zq + (*g_loss) * coef * (z - zq_value) where coef = 2*commitment/numel (model.py:105-107,132). */
+int vg_vq_bwd(const float* g_zq, const float* g_loss, const float* z, const float* codebook, const int64_t* idx,
+              int64_t rows, int d, float coef, float* dz, void* stream);
+
+/* ---- loss reductions (<arch>/model.py loss_function) ------------------------------------------- */
+/* out[0] (f64, zeroed) += sum (a-b)^2 over valid channels; a,b NHWC `dtype` [rows][cs]. */
+int vg_sqdiff_sum(const void* a, const void* b, int64_t rows, int cs, int c, int dtype, double* out, void* stream);
+/* da = (*g) * coef * (a - b) on valid channels, 0 on padding. */
+int vg_sqdiff_bwd(const void* a, const void* b, const float* g, float coef, int64_t rows, int cs, int c, int dtype,
+                  void* da, void* stream);
+/* out[0] += sum over x of f(x): mode 0: x ; 1: relu(1-x) ; 2: relu(1+x).  x f32 flat. */
+int vg_reduce_f32(const float* x, int64_t n, int mode, double* out, void* stream);
+/* dx = (*g)*coef*f'(x) for the same modes. */
+int vg_reduce_f32_bwd(const float* x, const float* g, float coef, int64_t n, int mode, float* dx, void* stream);
+/* z = mu + eps*exp(0.5*logvar);  kl[0] (f64) += sum(1 + lv - mu^2 - exp(lv))  (beta model.py:211-216,258). */
+int vg_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps, int64_t n, float* z, double* kl, void* stream);
+/* dmu = gz + (*gkl)*ckl*(-2mu)... see kernel; gradients of z and of the KL sum w.r.t. mu/logvar. */
+int vg_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* gz, const float* gkl,
+                      float ckl, int64_t n, float* dmu, float* dlogvar, void* stream);
+/* f64 scalar -> f32 scalar with scale: dst[0] = (float)(src[0]*scale). */
+int vg_scalar_finish(const double* src, double scale, float* dst, void* stream);
+
+/* ---- fused Adam over a flat parameter buffer (<arch>/main.py:34-44, torch.optim.Adam defaults) --- */
+int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, int step, float grad_scale, void* stream);
+
+/* ---- skinny linear (beta_vae_gans/model.py:74-75,87-88,107,139) --------------------------- */
+/* y[b][o] = sum_i x[b][i]*w[o][i] + bias[o]; all f32; weight-streaming (b small). */
+int vg_linear_fwd(const float* x, const float* w, const float* bias, float* y, int b, int in_f, int out_f, void* stream);
+int vg_linear_dgrad(const float* dy, const float* w, float* dx, int b, int in_f, int out_f, void* stream);
+int vg_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, int b, int in_f, int out_f, void* stream);
+
+/* ---- self attention (hierarchical_vae_gan/model.py:24-47) ---------------------------------- */
+/* o[b][i][:] = sum_j softmax_j(q_i.k_j) v[b][j][:]  (no 1/sqrt(d) scale); q,k: [b][hw][dqk_s], v,o: [b][hw][dv_s]
+ * NHWC `dtype`; lse: f32 [b][hw] (saved for backward). */
+int vg_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int b, int hw, int dqk, int dqk_s,
+                int dv, int dv_s, int dtype, void* stream);
+int vg_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
+                void* dk, void* dv_out, float* ws, int b, int hw, int dqk, int dqk_s, int dv, int dv_s, int dtype,
+                void* stream);
+size_t vg_attn_bwd_ws_bytes(int b, int hw, int dqk_s, int dv_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VG_API_H */

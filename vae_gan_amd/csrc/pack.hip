@@ -1,0 +1,221 @@
+// Weight packing, NCHW<->NHWC layout conversion and per-channel column sums.
+#include <stdarg.h>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void vg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vg_last_error(void) { return g_err; }
+extern "C" int vg_version(void) { return 100; }
+
+int vg_npad(int n);
+int vg_transposed_taps(const vg_conv_desc* d, int phase, signed char* dy, signed char* dx, int* rs);
+
+static int kc_of(int dtype) { return dtype == VG_BF16 ? 32 : 16; }
+static int cpad_of(int c, int dtype) { int kc = kc_of(dtype); return (int)vg_ceil_div(c, kc) * kc; }
+
+struct PackParams {
+  const float* w;
+  void* out;
+  int O, I, RS;          // master weight dims [O][I][RS]
+  int Npad, Cpad, ntaps, nphases, transposed;
+  int rs[4][16];
+};
+
+template <typename T> __global__ void pack_kernel(const PackParams p) {
+  const long total = (long)p.nphases * p.Npad * p.ntaps * p.Cpad;
+  T* out = (T*)p.out;
+  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    int c = (int)(t % p.Cpad);
+    long r1 = t / p.Cpad;
+    int tap = (int)(r1 % p.ntaps);
+    long r2 = r1 / p.ntaps;
+    int n = (int)(r2 % p.Npad);
+    int ph = (int)(r2 / p.Npad);
+    int rs = p.rs[ph][tap];
+    float v = 0.f;
+    if (!p.transposed) {
+      if (n < p.O && c < p.I) v = p.w[((size_t)n * p.I + c) * p.RS + rs];
+    } else {
+      if (n < p.I && c < p.O) v = p.w[((size_t)c * p.I + n) * p.RS + rs];
+    }
+    out[t] = Elt<T>::from_f(v);
+  }
+}
+
+static int fill_pack(const vg_conv_desc* d, int transposed, PackParams* p) {
+  memset(p, 0, sizeof(*p));
+  p->O = d->co; p->I = d->ci; p->RS = d->r * d->s; p->transposed = transposed;
+  if (!transposed) {
+    p->Npad = vg_npad(d->co); p->Cpad = cpad_of(d->ci, d->dtype); p->ntaps = d->r * d->s; p->nphases = 1;
+    for (int i = 0; i < p->ntaps; ++i) p->rs[0][i] = i;
+  } else {
+    p->Npad = vg_npad(d->ci); p->Cpad = cpad_of(d->co, d->dtype); p->nphases = d->stride * d->stride;
+    int nt = -1;
+    for (int ph = 0; ph < p->nphases; ++ph) {
+      signed char dy[16], dx[16];
+      int n = vg_transposed_taps(d, ph, dy, dx, p->rs[ph]);
+      if (n <= 0 || (nt >= 0 && n != nt)) return -1;
+      nt = n;
+    }
+    p->ntaps = nt;
+  }
+  return 0;
+}
+
+extern "C" size_t vg_conv_packed_bytes(const vg_conv_desc* d, int transposed) {
+  PackParams p;
+  if (!d || fill_pack(d, transposed, &p)) return 0;
+  return (size_t)p.nphases * p.Npad * p.ntaps * p.Cpad * vg_elt_size(d->dtype);
+}
+
+extern "C" int vg_conv_pack_weight(const vg_conv_desc* d, int transposed, const float* w_oihw, void* packed,
+                                   void* stream) {
+  VG_REQUIRE(d && w_oihw && packed, "pack_weight: null pointer");
+  VG_REQUIRE(d->r * d->s <= 16 && d->stride >= 1 && d->stride <= 2, "pack_weight: unsupported geometry");
+  PackParams p;
+  VG_REQUIRE(fill_pack(d, transposed, &p) == 0, "pack_weight: uneven tap count (k%d s%d p%d)", d->r, d->stride, d->pad);
+  p.w = w_oihw; p.out = packed;
+  const long total = (long)p.nphases * p.Npad * p.ntaps * p.Cpad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (d->dtype == VG_BF16) hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NCHW f32 <-> NHWC T.  One block handles 64 pixels x all channels of one image through LDS so that
+// both sides are coalesced (pixels contiguous in NCHW, channels contiguous in NHWC).
+// ---------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                                                  int C, int HW, int Cs) {
+  __shared__ float tile[64][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int cc = ty; cc < 32; cc += 4) {
+    int c = c0 + cc, pix = p0 + tx;
+    float v = 0.f;
+    if (c < C && pix < HW) v = src[((size_t)n * C + c) * HW + pix];
+    tile[tx][cc] = v;
+  }
+  __syncthreads();
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;   // 32 x 8
+  for (int pp = py; pp < 64; pp += 8) {
+    int pix = p0 + pp, c = c0 + cx;
+    if (pix < HW && c < Cs) dst[((size_t)n * HW + pix) * Cs + c] = Elt<T>::from_f(tile[pp][cx]);
+  }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst,
+                                                                                  int C, int HW, int Cs) {
+  __shared__ float tile[64][33];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  for (int pp = py; pp < 64; pp += 8) {
+    int pix = p0 + pp, c = c0 + cx;
+    float v = 0.f;
+    if (pix < HW && c < Cs) v = Elt<T>::to_f(src[((size_t)n * HW + pix) * Cs + c]);
+    tile[pp][cx] = v;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int cc = ty; cc < 32; cc += 4) {
+    int c = c0 + cc, pix = p0 + tx;
+    if (c < C && pix < HW) dst[((size_t)n * C + c) * HW + pix] = tile[tx][cc];
+  }
+}
+
+extern "C" int vg_nchw_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int cs, int dtype, void* stream) {
+  VG_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && cs >= c, "nchw_to_nhwc: bad arguments");
+  dim3 grid((unsigned)vg_ceil_div((int64_t)h * w, 64), (unsigned)vg_ceil_div(cs, 32), n);
+  if (dtype == VG_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, h * w, cs);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, c, h * w, cs);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h, int w, int cs, int dtype, void* stream) {
+  VG_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && cs >= c, "nhwc_to_nchw: bad arguments");
+  dim3 grid((unsigned)vg_ceil_div((int64_t)h * w, 64), (unsigned)vg_ceil_div(c, 32), n);
+  if (dtype == VG_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, c, h * w, cs);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, c, h * w, cs);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel column sum (bias gradients): out[c] = sum_m a[m][c]
+// thread = one 16-byte piece column; blocks stride over rows; f64 atomics into ws[cs]; finish to f32.
+// ---------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ a, int64_t rows, int cs,
+                                                                                double* __restrict__ ws) {
+  constexpr int PIECE = Elt<T>::PIECE;
+  const int ppr = cs / PIECE;                 // pieces per row
+  const int rpb = 256 / ppr > 0 ? 256 / ppr : 1;   // rows per block pass
+  const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+  if (rr >= rpb) return;
+  float acc[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) acc[e] = 0.f;
+  double dacc[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) dacc[e] = 0.0;
+  int cnt = 0;
+  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+    Piece<T> v;
+    v.v = *(const decltype(v.v)*)(a + (size_t)r * cs + pc * PIECE);
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) acc[e] += v.get(e);
+    if (++cnt == 64) {
+#pragma unroll
+      for (int e = 0; e < PIECE; ++e) { dacc[e] += acc[e]; acc[e] = 0.f; }
+      cnt = 0;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) unsafeAtomicAdd(&ws[pc * PIECE + e], dacc[e] + (double)acc[e]);
+}
+
+__global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n, double scale) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)(src[i] * scale);
+}
+
+extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws,
+                              void* stream) {
+  VG_REQUIRE(a && out && ws && rows > 0 && cs > 0 && c_valid <= cs, "channel_sum: bad arguments");
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_sum: channel stride %d unsupported", cs);
+  hipStream_t st = (hipStream_t)stream;
+  VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * cs, st));
+  const int ppr = cs / piece, rpb = 256 / ppr;
+  int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 8);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, rows, cs, ws);
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws);
+  VG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(d2f_kernel, dim3((c_valid + 255) / 256), dim3(256), 0, st, (const double*)ws, out, c_valid, 1.0);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_scalar_finish(const double* src, double scale, float* dst, void* stream) {
+  VG_REQUIRE(src && dst, "scalar_finish: null pointer");
+  hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, dst, 1, scale);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

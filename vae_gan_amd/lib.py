@@ -1,0 +1,126 @@
+"""ctypes binding of ``libvg_hip.so`` (C ABI declared in ``include/vg_api.h``).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised.  All calls enqueue on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvg_hip.so")
+
+VG_F32, VG_BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
+STATS_REPLICAS = 32
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("n", "h", "w", "oh", "ow", "ci", "co", "xcs", "ycs", "r", "s", "stride", "pad", "dtype")]
+
+
+_lib: Optional[C.CDLL] = None
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_D = C.c_double
+_DP = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); must list every symbol declared in include/vg_api.h
+SIGNATURES = {
+    "vg_last_error": (C.c_char_p, []),
+    "vg_version": (_I, []),
+    "vg_conv_packed_bytes": (C.c_size_t, [_DP, _I]),
+    "vg_conv_pack_weight": (_I, [_DP, _I, _P, _P, _P]),
+    "vg_conv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vg_conv_dgrad": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vg_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
+    "vg_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _P]),
+    "vg_channel_sum": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
+    "vg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "vg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "vg_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
+    "vg_add_inplace": (_I, [_P, _P, _L, _I, _P]),
+    "vg_vq_assign": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "vg_vq_gather": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
+    "vg_vq_ema_update": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "vg_vq_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _P, _P]),
+    "vg_sqdiff_sum": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "vg_sqdiff_bwd": (_I, [_P, _P, _P, _F, _L, _I, _I, _I, _P, _P]),
+    "vg_reduce_f32": (_I, [_P, _L, _I, _P, _P]),
+    "vg_reduce_f32_bwd": (_I, [_P, _P, _F, _L, _I, _P, _P]),
+    "vg_reparam_kl_fwd": (_I, [_P, _P, _P, _L, _P, _P, _P]),
+    "vg_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P]),
+    "vg_scalar_finish": (_I, [_P, _D, _P, _P]),
+    "vg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "vg_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "vg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "vg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "vg_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_attn_bwd_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
+}
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C vae_gan_amd/csrc` "
+                               "(there is no CPU fallback for the HIP path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("VG_DEV_PARTIAL") == "1" and not hasattr(lib, name):
+                continue               # development only: library built from a subset of the sources
+            fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().vg_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise RuntimeError(f"libvg_hip {what} failed (rc={rc}): {last_error()}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def vg_dtype(dt: torch.dtype) -> int:
+    if dt == torch.bfloat16:
+        return VG_BF16
+    if dt == torch.float32:
+        return VG_F32
+    raise TypeError(f"unsupported activation dtype {dt}")
+
+
+def kc_of(dt: torch.dtype) -> int:
+    """Channel-stride granule: one 64-byte K chunk."""
+    return 32 if dt == torch.bfloat16 else 16
+
+
+def pad_channels(c: int, dt: torch.dtype) -> int:
+    k = kc_of(dt)
+    return (c + k - 1) // k * k
