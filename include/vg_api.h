@@ -83,6 +83,9 @@ int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h, int w, int
 int vg_bn_finalize(const double* stats, int c, int cpad, int64_t count, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* stats[VG_STATS_REPLICAS][2][cpad] (f64, zeroed by caller) += per-channel sum / sum of squares of x:
+ * for a BatchNorm whose input is not a conv output (beta_vae_gans/model.py:117). */
+int vg_channel_stats(const void* x, double* stats, int64_t rows, int cs, int c, int cpad, int dtype, void* stream);
 /* y = act(x*scale[c] + shift[c] (+ res)); act per VG_ACT_*.  x,res,y: [rows][cs] `dtype`. */
 int vg_bn_act_fwd(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
                   int cs, int c, int act, int dtype, void* stream);
@@ -92,6 +95,8 @@ int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float
                      double* sums, int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream);
 /* Backward, pass 2: dx = gamma*invstd*(dz - sum_dz/n - xhat*sum_dzxhat/n); dres = dz (optional);
  * dgamma = sum_dzxhat, dbeta = sum_dz (f32 [c]). */
+/* NOTE: `sums` must be followed by 3*cpad f32 of scratch (coefficients), i.e. allocate
+ * VG_STATS_REPLICAS*2*cpad f64 + 3*cpad f32. */
 int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                     const float* gamma, const double* sums, void* dx, void* dres, float* dgamma, float* dbeta,
                     int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream);
@@ -111,10 +116,11 @@ int vg_vq_gather(const float* z, const float* codebook, const int64_t* idx, int6
 /* EMA + renormalise (model.py:114-129): cluster = cluster*decay + (1-decay)*counts; ema_w likewise;
  * codebook = ema_w / ((cluster+1e-5)/(n+k*1e-5)*n). */
 int vg_vq_ema_update(float* ema_cluster, float* ema_w, float* codebook, const float* counts, const float* esum,
-                     int k, int d, float decay, void* stream);
-/* dz = g_zq + (*g_loss) * coef * (z - zq_value) where coef = 2*commitment/numel (model.py:105-107,132). */
-int vg_vq_bwd(const float* g_zq, const float* g_loss, const float* z, const float* codebook, const int64_t* idx,
-              int64_t rows, int d, float coef, float* dz, void* stream);
+                     int k, int d, float decay, float* nsum_scratch /* 1 f32 */, void* stream);
+/* dz = g_zq + (*g_loss) * coef * (z - zq) where coef = 2*commitment/numel (model.py:105-107,132);
+ * zq is the forward's output (its value is the pre-EMA code vector).  g_zq / g_loss may be null. */
+int vg_vq_bwd(const float* g_zq, const float* g_loss, const float* z, const float* zq, int64_t n, float coef,
+              float* dz, void* stream);
 
 /* ---- loss reductions (<arch>/model.py loss_function) ------------------------------------------- */
 /* out[0] (f64, zeroed) += sum (a-b)^2 over valid channels; a,b NHWC `dtype` [rows][cs]. */

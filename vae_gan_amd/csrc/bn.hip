@@ -1,0 +1,375 @@
+// BatchNorm (training mode) finalize / apply / backward, LeakyReLU / residual fusion and small
+// elementwise helpers.  All of these are HBM-bandwidth kernels: 16-byte vector accesses, channel
+// index = (element index) % cs, per-channel f64 atomics spread over VG_STATS_REPLICAS copies.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int c, int cpad, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, int64_t* num_batches,
+                                   float* mean, float* invstd, float* scale, float* shift) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && num_batches != nullptr) *num_batches += 1;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < VG_STATS_REPLICAS; ++r) {
+    s1 += stats[((size_t)r * 2 + 0) * cpad + ch];
+    s2 += stats[((size_t)r * 2 + 1) * cpad + ch];
+  }
+  double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[ch] = (float)m;
+  invstd[ch] = is;
+  float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+  float sc = g * is;
+  scale[ch] = sc;
+  shift[ch] = b - (float)m * sc;
+  if (running_mean != nullptr) {
+    double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+
+extern "C" int vg_bn_finalize(const double* stats, int c, int cpad, int64_t count, const float* gamma, const float* beta,
+                              float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches,
+                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  VG_REQUIRE(stats && mean && invstd && scale && shift && c > 0 && cpad >= c && count > 0, "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, c, cpad,
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, mean, invstd,
+                     scale, shift);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int64_t npieces, int ppr, int c, int act) {
+  constexpr int PIECE = Elt<T>::PIECE;
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < npieces; q += (int64_t)gridDim.x * 256) {
+    const int ch0 = (int)(q % ppr) * PIECE;
+    Piece<T> v, r, o;
+    v.v = *(const decltype(v.v)*)(x + q * PIECE);
+    if (HAS_RES) r.v = *(const decltype(r.v)*)(res + q * PIECE);
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+      const int ch = ch0 + e;
+      float f = 0.f;
+      if (ch < c) {
+        f = v.get(e) * scale[ch] + shift[ch];
+        if (HAS_RES) f += r.get(e);
+        if (act == VG_ACT_LRELU) f = vg_lrelu(f);
+        else if (act == VG_ACT_SIGMOID) f = vg_sigmoid(f);
+      }
+      o.set(e, f);
+    }
+    *(decltype(o.v)*)(y + q * PIECE) = o.v;
+  }
+}
+
+static int ew_blocks(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b > 2048 * 4) b = 2048 * 4;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
+                             int cs, int c, int act, int dtype, void* stream) {
+  VG_REQUIRE(x && y && scale && shift && rows > 0 && cs >= c, "bn_act_fwd: bad arguments");
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(cs % piece == 0, "bn_act_fwd: channel stride %d not a multiple of %d", cs, piece);
+  const int ppr = cs / piece;
+  const int64_t np = rows * ppr;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(ew_blocks(np)), b(256);
+  if (dtype == VG_BF16) {
+    if (res) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, scale, shift, np, ppr, c, act);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, scale, shift, np, ppr, c, act);
+  } else {
+    if (res) hipLaunchKernelGGL((bn_act_fwd_kernel<float, true>), g, b, 0, st, (const float*)x, (const float*)res, (float*)y, scale, shift, np, ppr, c, act);
+    else hipLaunchKernelGGL((bn_act_fwd_kernel<float, false>), g, b, 0, st, (const float*)x, (const float*)nullptr, (float*)y, scale, shift, np, ppr, c, act);
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward pass 1: per-channel sums of dz and dz*xhat.
+// Block = 256 threads = (256/ppr') rows x ppr' piece-columns; every thread keeps PIECE channel
+// accumulators in registers over its rows, then the block combines through LDS and issues one f64
+// atomic per channel.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                            const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, double* __restrict__ sums,
+                                                            int64_t rows, int cs, int c, int cpad, int act) {
+  constexpr int PIECE = Elt<T>::PIECE;
+  __shared__ float red[256 * PIECE * 2];
+  const int ppr = cs / PIECE;                        // pieces per row (<= 256 guaranteed by launcher)
+  const int rpb = 256 / ppr;                         // rows handled per block pass
+  const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+  float a1[PIECE], a2[PIECE], mu[PIECE], is[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) {
+    a1[e] = 0.f; a2[e] = 0.f;
+    const int ch = pc * PIECE + e;
+    mu[e] = ch < c ? mean[ch] : 0.f;
+    is[e] = ch < c ? invstd[ch] : 0.f;
+  }
+  double d1[PIECE], d2[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) { d1[e] = 0.0; d2[e] = 0.0; }
+  if (rr < rpb) {
+    int cnt = 0;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+      const size_t off = (size_t)r * cs + pc * PIECE;
+      Piece<T> g, o, v;
+      g.v = *(const decltype(g.v)*)(dout + off);
+      o.v = *(const decltype(o.v)*)(y + off);
+      v.v = *(const decltype(v.v)*)(x + off);
+#pragma unroll
+      for (int e = 0; e < PIECE; ++e) {
+        float dz = g.get(e);
+        if (act == VG_ACT_LRELU && !(o.get(e) > 0.f)) dz *= VG_LRELU_SLOPE;
+        const float xh = (v.get(e) - mu[e]) * is[e];
+        a1[e] += dz;
+        a2[e] += dz * xh;
+      }
+      if (++cnt == 32) {
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) { d1[e] += a1[e]; d2[e] += a2[e]; a1[e] = 0.f; a2[e] = 0.f; }
+        cnt = 0;
+      }
+    }
+  }
+  // combine the rpb row-groups of this block through LDS, then one f64 atomic per channel per block
+  const int width = ppr * PIECE;
+  if (rr < rpb) {
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+      red[(rr * width + pc * PIECE + e) * 2 + 0] = (float)(d1[e] + (double)a1[e]);
+      red[(rr * width + pc * PIECE + e) * 2 + 1] = (float)(d2[e] + (double)a2[e]);
+    }
+  }
+  __syncthreads();
+  const int rep = blockIdx.x % VG_STATS_REPLICAS;
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < rpb; ++r) { t1 += red[(r * width + ch) * 2]; t2 += red[(r * width + ch) * 2 + 1]; }
+    unsafeAtomicAdd(&sums[((size_t)rep * 2 + 0) * cpad + ch], t1);
+    unsafeAtomicAdd(&sums[((size_t)rep * 2 + 1) * cpad + ch], t2);
+  }
+}
+
+extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+                                double* sums, int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream) {
+  VG_REQUIRE(dout && y && x && mean && invstd && sums && rows > 0 && cs >= c && cpad >= c, "bn_bwd_reduce: bad arguments");
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "bn_bwd_reduce: channel stride %d unsupported", cs);
+  const int rpb = 256 / (cs / piece);
+  int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 16);
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, sums, rows, cs, c, cpad, act);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, sums, rows, cs, c, cpad, act);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward pass 2
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int cpad, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                   float* __restrict__ coef /* [3][cpad]: a = gamma*invstd, m1 = sum_dz/n, m2 = sum_dzxh/n */,
+                                   float* dgamma, float* dbeta) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < VG_STATS_REPLICAS; ++r) {
+    s1 += sums[((size_t)r * 2 + 0) * cpad + ch];
+    s2 += sums[((size_t)r * 2 + 1) * cpad + ch];
+  }
+  coef[ch] = (gamma ? gamma[ch] : 1.f) * invstd[ch];
+  coef[cpad + ch] = (float)(s1 / count);
+  coef[2 * cpad + ch] = (float)(s2 / count);
+  if (dgamma) dgamma[ch] = (float)s2;
+  if (dbeta) dbeta[ch] = (float)s1;
+}
+
+template <typename T, bool HAS_DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                           const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           T* __restrict__ dx, T* __restrict__ dres, int64_t npieces,
+                                                           int ppr, int c, int cpad, int act) {
+  constexpr int PIECE = Elt<T>::PIECE;
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < npieces; q += (int64_t)gridDim.x * 256) {
+    const int ch0 = (int)(q % ppr) * PIECE;
+    Piece<T> g, o, v, rx, rr;
+    g.v = *(const decltype(g.v)*)(dout + q * PIECE);
+    o.v = *(const decltype(o.v)*)(y + q * PIECE);
+    v.v = *(const decltype(v.v)*)(x + q * PIECE);
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+      const int ch = ch0 + e;
+      float dz = 0.f, d = 0.f;
+      if (ch < c) {
+        dz = g.get(e);
+        if (act == VG_ACT_LRELU && !(o.get(e) > 0.f)) dz *= VG_LRELU_SLOPE;
+        const float xh = (v.get(e) - mean[ch]) * invstd[ch];
+        d = coef[ch] * (dz - coef[cpad + ch] - xh * coef[2 * cpad + ch]);
+      }
+      rx.set(e, d);
+      if (HAS_DRES) rr.set(e, dz);
+    }
+    *(decltype(rx.v)*)(dx + q * PIECE) = rx.v;
+    if (HAS_DRES) *(decltype(rr.v)*)(dres + q * PIECE) = rr.v;
+  }
+}
+
+extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+                               const float* gamma, const double* sums, void* dx, void* dres, float* dgamma, float* dbeta,
+                               int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream) {
+  VG_REQUIRE(dout && y && x && mean && invstd && sums && dx && rows > 0 && cs >= c && cpad >= c, "bn_bwd_apply: bad arguments");
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(cs % piece == 0, "bn_bwd_apply: channel stride %d unsupported", cs);
+  hipStream_t st = (hipStream_t)stream;
+  // coefficient scratch lives right behind the f64 sums (caller allocates [REPLICAS*2*cpad] f64 + 3*cpad f32)
+  float* coef = (float*)(sums + (size_t)VG_STATS_REPLICAS * 2 * cpad);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)rows, gamma, invstd, coef, dgamma, dbeta);
+  VG_LAUNCH_CHECK();
+  const int ppr = cs / piece;
+  const int64_t np = rows * ppr;
+  dim3 g(ew_blocks(np)), b(256);
+  if (dtype == VG_BF16) {
+    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, coef, (bf16_t*)dx, (bf16_t*)dres, np, ppr, c, cpad, act);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, coef, (bf16_t*)dx, (bf16_t*)nullptr, np, ppr, c, cpad, act);
+  } else {
+    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, coef, (float*)dx, (float*)dres, np, ppr, c, cpad, act);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, coef, (float*)dx, (float*)nullptr, np, ppr, c, cpad, act);
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ y, T* __restrict__ dx,
+                                                      int64_t npieces, int act) {
+  constexpr int PIECE = Elt<T>::PIECE;
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < npieces; q += (int64_t)gridDim.x * 256) {
+    Piece<T> g, o, r;
+    g.v = *(const decltype(g.v)*)(dout + q * PIECE);
+    o.v = *(const decltype(o.v)*)(y + q * PIECE);
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+      float d = g.get(e), yv = o.get(e);
+      if (act == VG_ACT_LRELU) d = yv > 0.f ? d : d * VG_LRELU_SLOPE;
+      else if (act == VG_ACT_SIGMOID) d = d * yv * (1.f - yv);
+      r.set(e, d);
+    }
+    *(decltype(r.v)*)(dx + q * PIECE) = r.v;
+  }
+}
+
+extern "C" int vg_act_bwd(const void* dout, const void* y, void* dx, int64_t n, int act, int dtype, void* stream) {
+  VG_REQUIRE(dout && y && dx && n > 0, "act_bwd: bad arguments");
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(n % piece == 0, "act_bwd: element count %lld not a multiple of %d", (long long)n, piece);
+  const int64_t np = n / piece;
+  if (dtype == VG_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(ew_blocks(np)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, (const bf16_t*)y, (bf16_t*)dx, np, act);
+  else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(ew_blocks(np)), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (const float*)y, (float*)dx, np, act);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_inplace_kernel(T* __restrict__ a, const T* __restrict__ b, int64_t npieces) {
+  constexpr int PIECE = Elt<T>::PIECE;
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < npieces; q += (int64_t)gridDim.x * 256) {
+    Piece<T> x, y2, r;
+    x.v = *(const decltype(x.v)*)(a + q * PIECE);
+    y2.v = *(const decltype(y2.v)*)(b + q * PIECE);
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) r.set(e, x.get(e) + y2.get(e));
+    *(decltype(r.v)*)(a + q * PIECE) = r.v;
+  }
+}
+
+extern "C" int vg_add_inplace(void* a, const void* b, int64_t n, int dtype, void* stream) {
+  VG_REQUIRE(a && b && n > 0, "add_inplace: bad arguments");
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(n % piece == 0, "add_inplace: element count not a multiple of %d", piece);
+  const int64_t np = n / piece;
+  if (dtype == VG_BF16) hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(ew_blocks(np)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a, (const bf16_t*)b, np);
+  else hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(ew_blocks(np)), dim3(256), 0, (hipStream_t)stream, (float*)a, (const float*)b, np);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel sum / sum of squares of an arbitrary NHWC tensor (BatchNorm that does not follow a
+// conv, e.g. beta_vae_gans/model.py:117 after the Linear projection).  Same layout as the conv stats.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int64_t rows,
+                                                            int cs, int c, int cpad) {
+  constexpr int PIECE = Elt<T>::PIECE;
+  __shared__ float red[256 * PIECE * 2];
+  const int ppr = cs / PIECE, rpb = 256 / ppr;
+  const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+  float a1[PIECE], a2[PIECE];
+  double d1[PIECE], d2[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) { a1[e] = 0.f; a2[e] = 0.f; d1[e] = 0.0; d2[e] = 0.0; }
+  if (rr < rpb) {
+    int cnt = 0;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+      Piece<T> v;
+      v.v = *(const decltype(v.v)*)(x + (size_t)r * cs + pc * PIECE);
+#pragma unroll
+      for (int e = 0; e < PIECE; ++e) { const float f = v.get(e); a1[e] += f; a2[e] += f * f; }
+      if (++cnt == 32) {
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) { d1[e] += a1[e]; d2[e] += a2[e]; a1[e] = 0.f; a2[e] = 0.f; }
+        cnt = 0;
+      }
+    }
+  }
+  const int width = ppr * PIECE;
+  if (rr < rpb) {
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) {
+      red[(rr * width + pc * PIECE + e) * 2 + 0] = (float)(d1[e] + (double)a1[e]);
+      red[(rr * width + pc * PIECE + e) * 2 + 1] = (float)(d2[e] + (double)a2[e]);
+    }
+  }
+  __syncthreads();
+  const int rep = blockIdx.x % VG_STATS_REPLICAS;
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < rpb; ++r) { t1 += red[(r * width + ch) * 2]; t2 += red[(r * width + ch) * 2 + 1]; }
+    unsafeAtomicAdd(&stats[((size_t)rep * 2 + 0) * cpad + ch], t1);
+    unsafeAtomicAdd(&stats[((size_t)rep * 2 + 1) * cpad + ch], t2);
+  }
+}
+
+extern "C" int vg_channel_stats(const void* x, double* stats, int64_t rows, int cs, int c, int cpad, int dtype, void* stream) {
+  VG_REQUIRE(x && stats && rows > 0 && cs >= c && cpad >= c, "channel_stats: bad arguments");
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_stats: channel stride %d unsupported", cs);
+  const int rpb = 256 / (cs / piece);
+  int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats, rows, cs, c, cpad);
+  else hipLaunchKernelGGL(channel_stats_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, stats, rows, cs, c, cpad);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

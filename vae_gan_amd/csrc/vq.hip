@@ -1,0 +1,233 @@
+// Vector quantiser kernels (reference: vq_vae_gan/model.py:68-134).
+//
+// vq_assign: fused  (|z|^2 + |E|^2) - 2 z.E  distance tile on the exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain) with a running per-lane argmin and one
+// wavefront shuffle to merge the two lane halves.  The [rows][K] distance matrix the reference
+// materialises (134 MB at B=64) never leaves registers.
+#include "common.h"
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void vq_assign_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                            int64_t rows, int K, int D, int64_t* __restrict__ idx) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int LD = D + 1;                       // padded row stride: conflict-free 4-byte column reads
+  float* sz = sm;                             // [NW*32][LD]
+  float* se = sz + NW * 32 * LD;              // [2][32][LD]
+  float* sb = se + 2 * 32 * LD;               // [2][32]  |E_k|^2
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31;
+  constexpr int NT = NW * 64;
+  const int64_t row0 = (int64_t)blockIdx.x * (NW * 32);
+
+  // stage the block's z rows
+  for (int q = tid; q < NW * 32 * (D / 4); q += NT) {
+    int r = q / (D / 4), c4 = q - r * (D / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row0 + r < rows) v = *(const f32x4*)(z + (size_t)(row0 + r) * D + c4 * 4);
+    float* dst = sz + r * LD + c4 * 4;
+    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+  }
+  auto stage_codes = [&](int tile, int buf) {
+    for (int q = tid; q < 32 * (D / 4); q += NT) {
+      int r = q / (D / 4), c4 = q - r * (D / 4);
+      int code = tile * 32 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (code < K) v = *(const f32x4*)(cb + (size_t)code * D + c4 * 4);
+      float* dst = se + (buf * 32 + r) * LD + c4 * 4;
+      dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+    }
+  };
+  stage_codes(0, 0);
+  __syncthreads();
+  // |z_row|^2 for this lane's row (column of the MFMA tile), sequential in k like a plain f32 sum
+  const float* zrow = sz + (wave * 32 + l32) * LD;
+  float zz = 0.f;
+  for (int k = 0; k < D; ++k) zz += zrow[k] * zrow[k];
+
+  float best = __builtin_inff();
+  int besti = 0;
+  const int ntiles = (K + 31) / 32;
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (tid < 32) {   // |E_k|^2 of the current tile
+      const float* er = se + (buf * 32 + tid) * LD;
+      float s = 0.f;
+      for (int k = 0; k < D; ++k) s += er[k] * er[k];
+      sb[buf * 32 + tid] = s;
+    }
+    if (t + 1 < ntiles) stage_codes(t + 1, buf ^ 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ea = se + (buf * 32 + l32) * LD + h;
+    const float* zb = zrow + h;
+#pragma unroll 8
+    for (int s = 0; s < D / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ea[2 * s], zb[2 * s], acc, 0, 0, 0);
+    __syncthreads();   // sb of this tile visible; next tile fully staged
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int code = t * 32 + cl;
+      const float dist = (zz + sb[buf * 32 + cl]) - 2.f * acc[r];
+      if (code < K && dist < best) { best = dist; besti = code; }
+    }
+  }
+  // merge the two lane halves (codes interleave in groups of 4): smaller distance, then smaller index
+  const float ob = __shfl_xor(best, 32, 64);
+  const int oi = __shfl_xor(besti, 32, 64);
+  if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  const int64_t row = row0 + wave * 32 + l32;
+  if (h == 0 && row < rows) idx[row] = besti;
+}
+
+extern "C" int vg_vq_assign(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx,
+                            void* stream) {
+  VG_REQUIRE(z && codebook && idx && rows > 0 && k > 0, "vq_assign: bad arguments");
+  VG_REQUIRE(d % 4 == 0 && d >= 4 && d <= 256, "vq_assign: embedding_dim %d unsupported (multiple of 4, <= 256)", d);
+  hipStream_t st = (hipStream_t)stream;
+  const int nw = d <= 128 ? 4 : 2;
+  const size_t lds = ((size_t)(nw * 32 + 64) * (d + 1) + 64) * sizeof(float);
+  const unsigned blocks = (unsigned)vg_ceil_div(rows, nw * 32);
+  if (nw == 4) {
+    static bool set4 = false;
+    if (!set4) { VG_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set4 = true; }
+    hipLaunchKernelGGL(vq_assign_kernel<4>, dim3(blocks), dim3(256), lds, st, z, codebook, rows, k, d, idx);
+  } else {
+    static bool set2 = false;
+    if (!set2) { VG_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set2 = true; }
+    hipLaunchKernelGGL(vq_assign_kernel<2>, dim3(blocks), dim3(128), lds, st, z, codebook, rows, k, d, idx);
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather + straight-through value + squared error + EMA statistics
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                        const int64_t* __restrict__ idx, int64_t rows, int K, int D,
+                                                        float* __restrict__ zq, double* __restrict__ sse,
+                                                        float* __restrict__ counts, float* __restrict__ esum) {
+  const int tpr = D / 4;                       // threads per row
+  const int rpb = 256 / tpr;
+  const int c4 = threadIdx.x % tpr, rr = threadIdx.x / tpr;
+  float local = 0.f;
+  if (rr < rpb) {
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+      int code = (int)idx[r];
+      if (code < 0) code = 0;
+      if (code >= K) code = K - 1;
+      const f32x4 zv = *(const f32x4*)(z + (size_t)r * D + c4 * 4);
+      const f32x4 qv = *(const f32x4*)(cb + (size_t)code * D + c4 * 4);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float diff = qv[e] - zv[e];
+        o[e] = zv[e] + diff;
+        local += diff * diff;
+      }
+      *(f32x4*)(zq + (size_t)r * D + c4 * 4) = o;
+      if (esum != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&esum[(size_t)code * D + c4 * 4 + e], zv[e]);
+        if (c4 == 0) unsafeAtomicAdd(&counts[code], 1.0f);
+      }
+    }
+  }
+  __shared__ double red[4];
+  double w = wave_sum_d((double)local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0 && sse != nullptr) unsafeAtomicAdd(sse, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int vg_vq_gather(const float* z, const float* codebook, const int64_t* idx, int64_t rows, int k, int d,
+                            float* zq, double* sse, float* counts, float* esum, void* stream) {
+  VG_REQUIRE(z && codebook && idx && zq && rows > 0 && k > 0, "vq_gather: bad arguments");
+  VG_REQUIRE(d % 4 == 0 && d / 4 <= 256, "vq_gather: embedding_dim %d unsupported", d);
+  VG_REQUIRE((counts == nullptr) == (esum == nullptr), "vq_gather: counts and esum must be given together");
+  const int rpb = 256 / (d / 4);
+  int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(vq_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, codebook, idx, rows, k,
+                     d, zq, sse, counts, esum);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EMA update: cluster sizes + their sum (one block), then the codebook rows (grid)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void vq_ema_cluster_kernel(float* __restrict__ cluster, const float* __restrict__ counts,
+                                                              int K, float decay, float* __restrict__ nsum) {
+  __shared__ float red[16];
+  float local = 0.f;
+  for (int i = threadIdx.x; i < K; i += 1024) {
+    float v = cluster[i] * decay + (1.f - decay) * counts[i];
+    cluster[i] = v;
+    local += v;
+  }
+  float w = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i];
+    *nsum = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_ema_weight_kernel(const float* __restrict__ cluster, float* __restrict__ ema_w,
+                                                            float* __restrict__ cb, const float* __restrict__ esum, int K,
+                                                            int D, float decay, const float* __restrict__ nsum) {
+  const float n = *nsum;
+  const int64_t total = (int64_t)K * D;
+  for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int code = (int)(t / D);
+    const float w = ema_w[t] * decay + (1.f - decay) * esum[t];
+    ema_w[t] = w;
+    const float cs = (cluster[code] + 1e-5f) / (n + (float)K * 1e-5f) * n;
+    cb[t] = w / cs;
+  }
+}
+
+extern "C" int vg_vq_ema_update(float* ema_cluster, float* ema_w, float* codebook, const float* counts, const float* esum,
+                                int k, int d, float decay, float* nsum, void* stream) {
+  VG_REQUIRE(ema_cluster && ema_w && codebook && counts && esum && nsum && k > 0 && d > 0, "vq_ema_update: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(vq_ema_cluster_kernel, dim3(1), dim3(1024), 0, st, ema_cluster, counts, k, decay, nsum);
+  VG_LAUNCH_CHECK();
+  int64_t total = (int64_t)k * d;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(vq_ema_weight_kernel, dim3(blocks), dim3(256), 0, st, ema_cluster, ema_w, codebook, esum, k, d, decay, nsum);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// dz = g_zq + (*g_loss)*coef*(z - zq)     (commitment term; straight-through passes g_zq unchanged)
+__global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ g_zq, const float* __restrict__ g_loss,
+                                                     const float* __restrict__ z, const float* __restrict__ zq, int64_t n4,
+                                                     float coef, float* __restrict__ dz) {
+  const float gl = g_loss ? *g_loss * coef : 0.f;
+  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
+    const f32x4 a = *(const f32x4*)(z + q * 4), b = *(const f32x4*)(zq + q * 4);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (g_zq) g = *(const f32x4*)(g_zq + q * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = g[e] + gl * (a[e] - b[e]);
+    *(f32x4*)(dz + q * 4) = o;
+  }
+}
+
+extern "C" int vg_vq_bwd(const float* g_zq, const float* g_loss, const float* z, const float* zq, int64_t n, float coef,
+                         float* dz, void* stream) {
+  VG_REQUIRE(z && zq && dz && n > 0 && n % 4 == 0, "vq_bwd: bad arguments");
+  int64_t n4 = n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(vq_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_zq, g_loss, z, zq, n4, coef, dz);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vg_channel_stats": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
@@ -54,8 +55,8 @@ SIGNATURES = {
     "vg_add_inplace": (_I, [_P, _P, _L, _I, _P]),
     "vg_vq_assign": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "vg_vq_gather": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
-    "vg_vq_ema_update": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
-    "vg_vq_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _P, _P]),
+    "vg_vq_ema_update": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
+    "vg_vq_bwd": (_I, [_P, _P, _P, _P, _L, _F, _P, _P]),
     "vg_sqdiff_sum": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "vg_sqdiff_bwd": (_I, [_P, _P, _P, _F, _L, _I, _I, _I, _P, _P]),
     "vg_reduce_f32": (_I, [_P, _L, _I, _P, _P]),

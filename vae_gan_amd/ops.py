@@ -1,0 +1,511 @@
+"""torch.autograd.Function wrappers around the C ABI of libvg_hip.so.
+
+PyTorch is the tensor allocator and autograd tape only: every arithmetic op of the hot path is
+a hand-written HIP kernel reached through ``vae_gan_amd.lib``.  Internal activations are NHWC
+tensors ``[N, H, W, Cs]`` (``Cs`` = channel count padded to a 64-byte granule) of the compute
+dtype (bf16 or f32); module boundaries convert from/to the reference's NCHW f32 tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+# bumped by the fused optimizers whenever parameters change outside torch's version counter
+PARAM_EPOCH = [0]
+
+_COMPUTE_DTYPE = [torch.bfloat16]
+
+
+def set_compute_dtype(dt: torch.dtype) -> None:
+    """bf16 (MFMA bf16, the benchmarked mode) or f32 (exact-f32 MFMA, the parity mode)."""
+    L.vg_dtype(dt)
+    _COMPUTE_DTYPE[0] = dt
+
+
+def compute_dtype() -> torch.dtype:
+    return _COMPUTE_DTYPE[0]
+
+
+def _npad(n: int) -> int:
+    return 32 if n <= 32 else (64 if n <= 64 else (n + 127) // 128 * 128)
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: the HIP path needs a tensor on an MI355X device (got {t.device}); "
+                           "there is no CPU fallback")
+
+
+# ----------------------------------------------------------------------------------------------
+# layout conversion
+# ----------------------------------------------------------------------------------------------
+def _nchw_to_nhwc(x: torch.Tensor, cs: int, dt: torch.dtype) -> torch.Tensor:
+    n, c, h, w = x.shape
+    out = torch.empty(n, h, w, cs, dtype=dt, device=x.device)
+    L.check(L.load().vg_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), n, c, h, w, cs, L.vg_dtype(dt), L.stream()), "nchw_to_nhwc")
+    return out
+
+
+def _nhwc_to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
+    n, h, w, cs = x.shape
+    out = torch.empty(n, c, h, w, dtype=torch.float32, device=x.device)
+    L.check(L.load().vg_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), n, c, h, w, cs, L.vg_dtype(x.dtype), L.stream()), "nhwc_to_nchw")
+    return out
+
+
+class ToNHWC(torch.autograd.Function):
+    """NCHW f32 -> NHWC compute dtype, channels zero-padded to ``cs``."""
+
+    @staticmethod
+    def forward(ctx, x, cs, dt):
+        _require_cuda(x, "to_nhwc")
+        ctx.c = x.shape[1]
+        return _nchw_to_nhwc(x.contiguous().float(), cs, dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _nhwc_to_nchw(g.contiguous(), ctx.c), None, None
+
+
+class ToNCHW(torch.autograd.Function):
+    """NHWC compute dtype -> NCHW f32 (first ``c`` channels)."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.cs, ctx.dt = x.shape[3], x.dtype
+        return _nhwc_to_nchw(x.contiguous(), c)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _nchw_to_nhwc(g.contiguous().float(), ctx.cs, ctx.dt), None
+
+
+def to_nhwc(x: torch.Tensor, dt: Optional[torch.dtype] = None) -> torch.Tensor:
+    dt = dt or compute_dtype()
+    return ToNHWC.apply(x, L.pad_channels(x.shape[1], dt), dt)
+
+
+def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
+    return ToNCHW.apply(x, c)
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+class PackedWeights:
+    """Per-layer cache of the packed (and transposed-packed) weight images in the compute dtype."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, weight: torch.Tensor, desc: L.ConvDesc, transposed: int, dt: torch.dtype) -> torch.Tensor:
+        key = (transposed, dt, desc.stride, desc.pad)
+        tag = (weight._version, PARAM_EPOCH[0], weight.data_ptr())
+        hit = self.cache.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        lib = L.load()
+        nbytes = lib.vg_conv_packed_bytes(C.byref(desc), transposed)
+        if nbytes == 0:
+            raise RuntimeError("conv: unsupported geometry for weight packing: " + L.last_error())
+        buf = torch.empty(nbytes // (2 if dt == torch.bfloat16 else 4), dtype=dt, device=weight.device)
+        L.check(lib.vg_conv_pack_weight(C.byref(desc), transposed, weight.data_ptr(), buf.data_ptr(), L.stream()), "pack_weight")
+        self.cache[key] = (tag, buf)
+        return buf
+
+
+def _conv_desc(n, h, w, ci, co, k, stride, pad, xcs, ycs, dt) -> L.ConvDesc:
+    oh = (h + 2 * pad - k) // stride + 1
+    ow = (w + 2 * pad - k) // stride + 1
+    return L.ConvDesc(n=n, h=h, w=w, oh=oh, ow=ow, ci=ci, co=co, xcs=xcs, ycs=ycs, r=k, s=k, stride=stride, pad=pad,
+                      dtype=L.vg_dtype(dt))
+
+
+def _stats_buf(npad: int, device) -> torch.Tensor:
+    return torch.zeros(L.STATS_REPLICAS * 2 * npad, dtype=torch.float64, device=device)
+
+
+def _act_bwd(g: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
+    out = torch.empty_like(y)
+    L.check(L.load().vg_act_bwd(g.data_ptr(), y.data_ptr(), out.data_ptr(), y.numel(), act, L.vg_dtype(y.dtype), L.stream()), "act_bwd")
+    return out
+
+
+def _channel_sum(t: torch.Tensor, c: int) -> torch.Tensor:
+    cs = t.shape[-1]
+    rows = t.numel() // cs
+    out = torch.empty(c, dtype=torch.float32, device=t.device)
+    ws = torch.empty(cs, dtype=torch.float64, device=t.device)
+    L.check(L.load().vg_channel_sum(t.data_ptr(), rows, cs, c, L.vg_dtype(t.dtype), out.data_ptr(), ws.data_ptr(), L.stream()), "channel_sum")
+    return out
+
+
+def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape) -> torch.Tensor:
+    lib = L.load()
+    ws = torch.empty(lib.vg_conv_wgrad_ws_bytes(C.byref(desc)) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+    L.check(lib.vg_conv_wgrad(C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), L.stream()), "conv_wgrad")
+    return dw
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act(conv2d(x, W) + b) on NHWC tensors; optionally emits BatchNorm statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs):
+        _require_cuda(x, "conv2d")
+        x = x.contiguous()
+        n, h, w, xcs = x.shape
+        co, ci, k, _ = weight.shape
+        dt = x.dtype
+        ycs = L.pad_channels(co, dt)
+        d = _conv_desc(n, h, w, ci, co, k, stride, pad, xcs, ycs, dt)
+        wp = packs.get(weight, d, 0, dt)
+        y = torch.empty(n, d.oh, d.ow, ycs, dtype=dt, device=x.device)
+        stats = _stats_buf(_npad(co), x.device) if want_stats else None
+        L.check(L.load().vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(), L.ptr(stats),
+                                     act, 0, L.stream()), "conv_fwd")
+        ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
+        ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        x, weight, y = ctx.saved_tensors
+        d, lib = ctx.d, L.load()
+        gy = gy.contiguous()
+        if ctx.act != L.ACT_NONE:
+            gy = _act_bwd(gy, y, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wpt = ctx.packs.get(weight, d, 1, x.dtype)
+            dx = torch.empty_like(x)
+            L.check(lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None, L.ACT_NONE, 0,
+                                      L.stream()), "conv_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(d, x, gy, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(gy, d.co)
+        return dx, dw, db, None, None, None, None, None
+
+
+class ConvTranspose2dFn(torch.autograd.Function):
+    """y = act(conv_transpose2d(x, W) + b): the dgrad kernel of the conv object W[O=in][I=out]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs):
+        _require_cuda(x, "conv_transpose2d")
+        x = x.contiguous()
+        n, h, w, xcs = x.shape
+        cin_t, cout_t, k, _ = weight.shape
+        dt = x.dtype
+        oh, ow = (h - 1) * stride - 2 * pad + k, (w - 1) * stride - 2 * pad + k
+        ycs = L.pad_channels(cout_t, dt)
+        d = _conv_desc(n, oh, ow, cout_t, cin_t, k, stride, pad, ycs, xcs, dt)
+        if d.oh != h or d.ow != w:
+            raise RuntimeError("conv_transpose2d: unsupported geometry (output_padding != 0)")
+        wpt = packs.get(weight, d, 1, dt)
+        y = torch.empty(n, oh, ow, ycs, dtype=dt, device=x.device)
+        stats = _stats_buf(_npad(cout_t), x.device) if want_stats else None
+        L.check(L.load().vg_conv_dgrad(C.byref(d), x.data_ptr(), wpt.data_ptr(), L.ptr(bias), y.data_ptr(), L.ptr(stats),
+                                       act, 0, L.stream()), "convT_fwd")
+        ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
+        ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, gy, _gstats):
+        x, weight, y = ctx.saved_tensors
+        d, lib = ctx.d, L.load()
+        gy = gy.contiguous()
+        if ctx.act != L.ACT_NONE:
+            gy = _act_bwd(gy, y, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = ctx.packs.get(weight, d, 0, x.dtype)
+            dx = torch.empty_like(x)
+            L.check(lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None, L.ACT_NONE, 0,
+                                    L.stream()), "convT_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(d, gy, x, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _channel_sum(gy, d.ci)
+        return dx, dw, db, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm (+ residual) + activation
+# ----------------------------------------------------------------------------------------------
+def channel_stats(x: torch.Tensor, c: int) -> torch.Tensor:
+    cs = x.shape[-1]
+    rows = x.numel() // cs
+    npad = _npad(c)
+    stats = _stats_buf(npad, x.device)
+    L.check(L.load().vg_channel_stats(x.data_ptr(), stats.data_ptr(), rows, cs, c, npad, L.vg_dtype(x.dtype), L.stream()), "channel_stats")
+    return stats
+
+
+class BNActFn(torch.autograd.Function):
+    """y = act(batchnorm_train(x) (+ res)); statistics come from the producing conv's epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, stats, gamma, beta, res, running_mean, running_var, nbt, eps, momentum, act, c):
+        lib = L.load()
+        x = x.contiguous()
+        cs = x.shape[-1]
+        rows = x.numel() // cs
+        cpad = stats.numel() // (L.STATS_REPLICAS * 2)
+        vec = torch.empty(4, c, dtype=torch.float32, device=x.device)   # mean, invstd, scale, shift
+        L.check(lib.vg_bn_finalize(stats.data_ptr(), c, cpad, rows, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                   L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), vec[0].data_ptr(),
+                                   vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), L.stream()), "bn_finalize")
+        y = torch.empty_like(x)
+        if res is not None:
+            res = res.contiguous()
+        L.check(lib.vg_bn_act_fwd(x.data_ptr(), L.ptr(res), y.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), rows, cs, c,
+                                  act, L.vg_dtype(x.dtype), L.stream()), "bn_act_fwd")
+        ctx.c, ctx.cpad, ctx.act, ctx.has_res = c, cpad, act, res is not None
+        ctx.save_for_backward(x, y, vec, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, vec, gamma = ctx.saved_tensors
+        lib = L.load()
+        gy = gy.contiguous()
+        cs = x.shape[-1]
+        rows = x.numel() // cs
+        c, cpad = ctx.c, ctx.cpad
+        sums = torch.zeros(L.STATS_REPLICAS * 2 * cpad + 2 * cpad, dtype=torch.float64, device=x.device)
+        dtc = L.vg_dtype(x.dtype)
+        L.check(lib.vg_bn_bwd_reduce(gy.data_ptr(), y.data_ptr(), x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
+                                     sums.data_ptr(), rows, cs, c, cpad, ctx.act, dtc, L.stream()), "bn_bwd_reduce")
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        L.check(lib.vg_bn_bwd_apply(gy.data_ptr(), y.data_ptr(), x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
+                                    gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(), L.ptr(dres), dgb[0].data_ptr(),
+                                    dgb[1].data_ptr(), rows, cs, c, cpad, ctx.act, dtc, L.stream()), "bn_bwd_apply")
+        return dx, None, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
+
+
+def bn_eval_act(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, act: int, c: int,
+                res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inference-mode BatchNorm (+res) + activation: per-channel affine from the running statistics.
+    (The [C]-sized scale/shift vectors are formed with torch ops; the tensor pass is the HIP kernel.)"""
+    scale = (gamma * torch.rsqrt(running_var + eps)).float().contiguous()
+    shift = (beta - running_mean * scale).float().contiguous()
+    y = torch.empty_like(x)
+    cs = x.shape[-1]
+    L.check(L.load().vg_bn_act_fwd(x.data_ptr(), L.ptr(res), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                   x.numel() // cs, cs, c, act, L.vg_dtype(x.dtype), L.stream()), "bn_act_fwd")
+    return y
+
+
+class AddFn(torch.autograd.Function):
+    """a + b on NHWC activations (hand-written kernel; used where a block output fans in)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = a.contiguous().clone()
+        L.check(L.load().vg_add_inplace(out.data_ptr(), b.contiguous().data_ptr(), out.numel(), L.vg_dtype(out.dtype), L.stream()), "add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+# ----------------------------------------------------------------------------------------------
+# vector quantiser
+# ----------------------------------------------------------------------------------------------
+class VectorQuantizeFn(torch.autograd.Function):
+    """vq_vae_gan/model.py:68-134 on NCHW f32 input: indices, straight-through output, VQ loss and the
+    in-place EMA codebook update (when ``training``)."""
+
+    @staticmethod
+    def forward(ctx, z, codebook, ema_cluster, ema_w, commitment, decay, training):
+        _require_cuda(z, "vector_quantizer")
+        lib = L.load()
+        z = z.contiguous().float()
+        b, d, h, w = z.shape
+        k = codebook.shape[0]
+        rows = b * h * w
+        dev = z.device
+        flat = torch.empty(rows, d, dtype=torch.float32, device=dev)
+        L.check(lib.vg_nchw_to_nhwc(z.data_ptr(), flat.data_ptr(), b, d, h, w, d, L.VG_F32, L.stream()), "vq.flatten")
+        idx = torch.empty(rows, dtype=torch.int64, device=dev)
+        L.check(lib.vg_vq_assign(flat.data_ptr(), codebook.data_ptr(), rows, k, d, idx.data_ptr(), L.stream()), "vq_assign")
+        zq_flat = torch.empty_like(flat)
+        scal = torch.zeros(2, dtype=torch.float64, device=dev)       # [sse, unused]
+        counts = esum = None
+        if training:
+            buf = torch.zeros(k * (d + 1) + 1, dtype=torch.float32, device=dev)
+            counts, esum, nsum = buf[:k], buf[k:k + k * d], buf[k + k * d:]
+        L.check(lib.vg_vq_gather(flat.data_ptr(), codebook.data_ptr(), idx.data_ptr(), rows, k, d, zq_flat.data_ptr(),
+                                 scal.data_ptr(), L.ptr(counts), L.ptr(esum), L.stream()), "vq_gather")
+        if training:
+            L.check(lib.vg_vq_ema_update(ema_cluster.data_ptr(), ema_w.data_ptr(), codebook.data_ptr(), counts.data_ptr(),
+                                         esum.data_ptr(), k, d, decay, nsum.data_ptr(), L.stream()), "vq_ema_update")
+        zq = torch.empty_like(z)
+        L.check(lib.vg_nhwc_to_nchw(zq_flat.data_ptr(), zq.data_ptr(), b, d, h, w, d, L.VG_F32, L.stream()), "vq.unflatten")
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        L.check(lib.vg_scalar_finish(scal.data_ptr(), (1.0 + commitment) / z.numel(), loss.data_ptr(), L.stream()), "vq.loss")
+        ctx.coef = 2.0 * commitment / z.numel()
+        ctx.save_for_backward(z, zq)
+        idx = idx.view(b, h, w)
+        ctx.mark_non_differentiable(idx)
+        return zq, loss, idx
+
+    @staticmethod
+    def backward(ctx, g_zq, g_loss, _gidx):
+        z, zq = ctx.saved_tensors
+        dz = torch.empty_like(z)
+        g_zq = g_zq.contiguous() if g_zq is not None else None
+        g_loss = g_loss.contiguous().float() if g_loss is not None else None
+        L.check(L.load().vg_vq_bwd(L.ptr(g_zq), L.ptr(g_loss), z.data_ptr(), zq.data_ptr(), z.numel(), ctx.coef,
+                                   dz.data_ptr(), L.stream()), "vq_bwd")
+        return dz, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# loss reductions (0-dim f32 device tensors; no host sync)
+# ----------------------------------------------------------------------------------------------
+def _finish(acc: torch.Tensor, scale: float) -> torch.Tensor:
+    out = torch.empty((), dtype=torch.float32, device=acc.device)
+    L.check(L.load().vg_scalar_finish(acc.data_ptr(), scale, out.data_ptr(), L.stream()), "scalar_finish")
+    return out
+
+
+class MSEFn(torch.autograd.Function):
+    """mean((a-b)^2) over two same-shaped f32 tensors (F.mse_loss, <arch>/model.py loss_function)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_cuda(a, "mse")
+        if a.shape != b.shape:
+            # same failure mode as the reference (beta_vae_gans/model.py:255 raises on 128 vs 256)
+            raise RuntimeError(f"The size of tensor a {tuple(a.shape)} must match the size of tensor b {tuple(b.shape)}")
+        a, b = a.contiguous().float(), b.contiguous().float()
+        n = a.numel()
+        if n % 4:
+            raise RuntimeError("mse: element count must be a multiple of 4")
+        acc = torch.zeros(1, dtype=torch.float64, device=a.device)
+        L.check(L.load().vg_sqdiff_sum(a.data_ptr(), b.data_ptr(), n // 4, 4, 4, L.VG_F32, acc.data_ptr(), L.stream()), "sqdiff_sum")
+        ctx.save_for_backward(a, b)
+        return _finish(acc, 1.0 / n)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        n = a.numel()
+        g = g.contiguous().float()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty_like(a)
+            L.check(L.load().vg_sqdiff_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), 2.0 / n, n // 4, 4, 4, L.VG_F32,
+                                           da.data_ptr(), L.stream()), "sqdiff_bwd")
+        if ctx.needs_input_grad[1]:
+            db = torch.empty_like(b)
+            L.check(L.load().vg_sqdiff_bwd(b.data_ptr(), a.data_ptr(), g.data_ptr(), 2.0 / n, n // 4, 4, 4, L.VG_F32,
+                                           db.data_ptr(), L.stream()), "sqdiff_bwd")
+        return da, db
+
+
+class MeanFn(torch.autograd.Function):
+    """scale * mean(f(x)) with f = identity (mode 0), relu(1-x) (1) or relu(1+x) (2)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, scale):
+        _require_cuda(x, "mean")
+        x = x.contiguous().float()
+        acc = torch.zeros(1, dtype=torch.float64, device=x.device)
+        L.check(L.load().vg_reduce_f32(x.data_ptr(), x.numel(), mode, acc.data_ptr(), L.stream()), "reduce_f32")
+        ctx.mode, ctx.scale = mode, scale
+        ctx.save_for_backward(x)
+        return _finish(acc, scale / x.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        g = g.contiguous().float()
+        L.check(L.load().vg_reduce_f32_bwd(x.data_ptr(), g.data_ptr(), ctx.scale / x.numel(), x.numel(), ctx.mode,
+                                           dx.data_ptr(), L.stream()), "reduce_f32_bwd")
+        return dx, None, None
+
+
+def mse(a, b):
+    return MSEFn.apply(a, b)
+
+
+def hinge_d(disc_real, disc_fake):
+    """mean(relu(1 - real)) + mean(relu(1 + fake))   (<arch>/model.py loss_function, D branch)."""
+    return MeanFn.apply(disc_real, 1, 1.0) + MeanFn.apply(disc_fake, 2, 1.0)
+
+
+def neg_mean(x):
+    return MeanFn.apply(x, 0, -1.0)
+
+
+class ReparamFn(torch.autograd.Function):
+    """z = mu + eps * exp(0.5 * logvar) (beta_vae_gans/model.py:211-216)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        _require_cuda(mu, "reparameterize")
+        mu, logvar, eps = mu.contiguous().float(), logvar.contiguous().float(), eps.contiguous().float()
+        z = torch.empty_like(mu)
+        L.check(L.load().vg_reparam_kl_fwd(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), mu.numel(), z.data_ptr(), None,
+                                           L.stream()), "reparam")
+        ctx.save_for_backward(mu, logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        mu, logvar, eps = ctx.saved_tensors
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        L.check(L.load().vg_reparam_kl_bwd(mu.data_ptr(), logvar.data_ptr(), eps.data_ptr(), gz.contiguous().data_ptr(), None,
+                                           0.0, mu.numel(), dmu.data_ptr(), dlv.data_ptr(), L.stream()), "reparam_bwd")
+        return dmu, dlv, None
+
+
+class KLFn(torch.autograd.Function):
+    """-0.5 * mean(1 + logvar - mu^2 - exp(logvar)) (beta_vae_gans/model.py:258)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        _require_cuda(mu, "kl")
+        mu, logvar = mu.contiguous().float(), logvar.contiguous().float()
+        acc = torch.zeros(1, dtype=torch.float64, device=mu.device)
+        L.check(L.load().vg_reparam_kl_fwd(mu.data_ptr(), logvar.data_ptr(), None, mu.numel(), None, acc.data_ptr(),
+                                           L.stream()), "kl")
+        ctx.save_for_backward(mu, logvar)
+        return _finish(acc, -0.5 / mu.numel())
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(mu)
+        g = g.contiguous().float()
+        L.check(L.load().vg_reparam_kl_bwd(mu.data_ptr(), logvar.data_ptr(), None, None, g.data_ptr(), -0.5 / mu.numel(),
+                                           mu.numel(), dmu.data_ptr(), dlv.data_ptr(), L.stream()), "kl_bwd")
+        return dmu, dlv
+
+
+def reparameterize(mu, logvar, eps):
+    return ReparamFn.apply(mu, logvar, eps)
+
+
+def kl_divergence(mu, logvar):
+    return KLFn.apply(mu, logvar)
