@@ -1,0 +1,67 @@
+"""GPU tier: the full VQ-VAE-GAN train step (vq_vae_gan/main.py:75-111 semantics) on the HIP engine
+against the golden captured from the reference model + torch.optim.Adam (two iterations, B=2, 64x64)."""
+import pytest
+import torch
+
+from conftest import load_golden, as_t, close_l2
+from vae_gan_amd.testing import fill_state_dict, digest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dtype):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from vae_gan_amd import ops
+    from vae_gan_amd.vq_vae_gan.model import VQVAEGAN
+    from vae_gan_amd.vq_vae_gan.config import Config
+    from vae_gan_amd.train import build_optimizers
+    ops.set_compute_dtype(dtype)
+    cfg = Config()
+    model = VQVAEGAN(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict()))
+    model.cuda().train()
+    opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+    return model, opt_g, opt_d
+
+
+def test_vq_step_f32_matches_reference():
+    from vae_gan_amd.train import vq_train_step
+    g = load_golden("vq_step_64")
+    model, opt_g, opt_d = _setup(torch.float32)
+    images = as_t(g["images"]).cuda()
+    for it in range(2):
+        dl, gl, idx2 = vq_train_step(model, images, opt_g, opt_d, elide_d_wgrad=(it == 1))
+        torch.cuda.synchronize()
+        mine = {"d_loss": dl["total"], "d_recon": dl["recon"], "g_loss": gl["total"], "recon": gl["recon"],
+                "vq": gl["vq"], "adv": gl["adv"]}
+        for k, v in mine.items():
+            ref = float(g[f"it{it}_{k}"])
+            tol = max(1e-4, 4 * float(g[f"noise:it{it}_{k}"]))
+            assert abs(float(v) - ref) <= tol * max(abs(ref), 1e-3), (it, k, float(v), ref, tol)
+        match = (idx2.cpu() == as_t(g[f"it{it}_idx2"])).float().mean().item()
+        assert match >= (1.0 if it == 0 else float(g["idxeq64:it1_idx2"]) - 0.02), (it, match)
+    sd = model.state_dict()
+    noise = max(float(g["noise:it1_recon_img"]), 1e-4)
+    for key, ref in g.items():
+        if key.startswith("sd:") and sd[key[3:]].dtype == torch.int64:
+            assert int(sd[key[3:]]) == int(ref), key       # BN counters: generator +2/iter, discriminator +3/iter
+        elif key.startswith("sdd:"):
+            d = digest(key[4:], sd[key[4:]])
+            assert abs(d[0] - ref[0]) <= max(1e-4, 4 * noise) * max(ref[0], 1e-6), key
+    from vae_gan_amd import ops
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+def test_vq_step_bf16_close_to_reference():
+    """bf16 mode: first-iteration losses within 2e-2 of the fp32 reference (north_star bf16 tolerance)."""
+    from vae_gan_amd.train import vq_train_step
+    g = load_golden("vq_step_64")
+    model, opt_g, opt_d = _setup(torch.bfloat16)
+    images = as_t(g["images"]).cuda()
+    dl, gl, idx2 = vq_train_step(model, images, opt_g, opt_d)
+    torch.cuda.synchronize()
+    for k, v in {"d_loss": dl["total"], "g_loss": gl["total"], "recon": gl["recon"], "vq": gl["vq"]}.items():
+        ref = float(g[f"it0_{k}"])
+        assert abs(float(v) - ref) <= 2e-2 * max(abs(ref), 1e-3), (k, float(v), ref)
+    assert all(torch.isfinite(p).all() for p in model.parameters())

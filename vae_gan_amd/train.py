@@ -1,0 +1,85 @@
+"""The GAN training step of <arch>/main.py:68-111 on the HIP engine, single GPU or data parallel.
+
+One process per GPU; gradients of each optimizer live in one flat buffer (``optim.FlatAdam``)
+that is all-reduced in a few large slices on a side stream while nothing else waits on the host.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .optim import FlatAdam, StepLR
+
+
+def build_optimizers(model, config):
+    """<arch>/main.py:34-48: Adam(encoder+decoder, lr) and Adam(discriminator, lr/2), betas from the config."""
+    opt_g = FlatAdam(list(model.encoder.parameters()) + list(model.decoder.parameters()), lr=config.lr,
+                     betas=(config.beta1, config.beta2))
+    opt_d = FlatAdam(model.discriminator.parameters(), lr=config.lr / 2, betas=(config.beta1, config.beta2))
+    return opt_g, opt_d, StepLR(opt_g, 30, 0.5), StepLR(opt_d, 30, 0.5)
+
+
+class DataParallel:
+    """Gradient exchange for one process per GPU.  ``reduce(opt)`` averages ``opt.flat_g`` over the
+    group in ``n_slices`` contiguous all-reduces (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, group=None, slice_bytes: int = 64 << 20):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.slice_elems = max(1, slice_bytes // 4)
+
+    def broadcast_model(self, model):
+        if self.world == 1:
+            return
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0, group=self.group)
+
+    def reduce(self, opt: FlatAdam):
+        if self.world == 1:
+            return 1.0
+        flat = opt.flat_g
+        handles = []
+        for s in range(0, flat.numel(), self.slice_elems):
+            handles.append(dist.all_reduce(flat[s:s + self.slice_elems], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for h in handles:
+            h.wait()
+        return 1.0 / self.world      # folded into the Adam kernel as grad_scale
+
+
+@contextlib.contextmanager
+def frozen(module):
+    """Disable parameter gradients of ``module`` (the discriminator during the generator step: the
+    reference computes those weight gradients and throws them away at the next zero_grad)."""
+    flags = [p.requires_grad for p in module.parameters()]
+    for p in module.parameters():
+        p.requires_grad_(False)
+    try:
+        yield
+    finally:
+        for p, f in zip(module.parameters(), flags):
+            p.requires_grad_(f)
+
+
+def vq_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[DataParallel] = None,
+                  elide_d_wgrad: bool = True):
+    """vq_vae_gan/main.py:75-111.  Returns (d_loss_dict, g_loss_dict, indices) with device scalars."""
+    # ---- discriminator step
+    opt_d.zero_grad()
+    recon, _, _, vq_loss, _ = model(images)
+    disc_real = model.discriminator(images)
+    disc_fake = model.discriminator(recon.detach())
+    d_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=False)
+    d_loss['total'].backward()
+    opt_d.step(dp.reduce(opt_d) if dp else 1.0)
+    # ---- generator step (second full forward: EMA + BatchNorm statistics update again)
+    opt_g.zero_grad()
+    recon, _, _, vq_loss, indices = model(images)
+    with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
+        disc_fake = model.discriminator(recon)
+        g_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=True)
+        g_loss['total'].backward()
+    opt_g.step(dp.reduce(opt_g) if dp else 1.0)
+    return d_loss, g_loss, indices
