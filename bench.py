@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Throughput bench of the VQ-VAE-GAN training step (BASELINE.json configs[1]:
+num_embeddings=512, embedding_dim=64, commitment_cost=0.25, batch 64 per GPU, bf16, 256x256
+synthetic RGB) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line: whole-job train images/s (weak scaling: 64 images per GPU), plus
+ * "roofline": algorithmic FLOPs of the dominant kernel (the 128x128-tile bf16 implicit-GEMM conv)
+   divided by its HIP-event-timed launch durations inside the timed region, against the 2.5 PFLOP/s
+   dense bf16 MFMA peak;
+ * "cpu_baseline": the CPU oracle's train step (oracle/vaegan_oracle.py, a port of the reference
+   step) timed on this host on a bounded sample (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+GF_PER_IMG_LITERAL = 446.9         # reference schedule, fwd F + bwd 2F
+GF_PER_IMG_NECESSARY = 391.7       # same minus D-wgrad in the G phase and the repeated encoder fwd
+
+
+def cpu_baseline(batch, size, threads):
+    """One oracle train step (after one untimed step at the smallest size to warm torch) on CPU."""
+    from oracle import vaegan_oracle as O
+    from vae_gan_amd.testing import fill_state_dict, synthetic_images
+    torch.set_num_threads(threads)
+    sd = fill_state_dict(O.vq_template())
+    imgs = synthetic_images(batch, size, seed=7)
+    opt = {"g": {}, "d": {}}
+    O.vq_train_step(sd, synthetic_images(1, 32, seed=8), O.VQ_DEFAULT_CFG, {"g": {}, "d": {}})
+    t0 = time.perf_counter()
+    O.vq_train_step(sd, imgs, O.VQ_DEFAULT_CFG, opt)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 oracle train step (D+G, fp32, torch CPU), batch {batch} at {size}x{size}, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from vae_gan_amd import ops
+    from vae_gan_amd.train import DataParallel, build_optimizers, vq_train_step
+    from vae_gan_amd.vq_vae_gan.config import Config
+    from vae_gan_amd.vq_vae_gan.model import VQVAEGAN
+
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    cfg = Config()
+    cfg.image_size, cfg.batch_size = args.size, args.batch
+    torch.manual_seed(42)
+    model = VQVAEGAN(cfg).cuda().train()
+    dp = DataParallel() if world > 1 else None
+    if dp:
+        dp.broadcast_model(model)
+    opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42 + rank)
+    images = torch.rand(args.batch, 3, args.size, args.size, generator=g, device="cuda")   # resident in HBM
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        vq_train_step(model, images, opt_g, opt_d, dp)
+    prof = None
+    if not args.no_kernel_timing:
+        prof = ops.KernelProfile()
+        ops.PROFILE[0] = prof
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d_loss, g_loss, _ = vq_train_step(model, images, opt_g, opt_d, dp)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.PROFILE[0] = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    finite = bool(torch.isfinite(g_loss["total"]).item() and torch.isfinite(d_loss["total"]).item())
+
+    if rank == 0:
+        imgs_per_s = world * args.batch * args.steps / dt
+        roof = None
+        kernels = {}
+        if prof is not None:
+            summ = prof.summary()
+            for name, d in summ.items():
+                kernels[name] = {"launches": d["launches"], "avg_ms": d["ms"] / d["launches"],
+                                 "tflops": d["flops"] / d["ms"] / 1e9}
+            dom = max((n for n in summ if n.startswith("igemm")), key=lambda n: summ[n]["ms"])
+            ach = summ[dom]["flops"] / summ[dom]["ms"] / 1e9
+            roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                    "launches_per_step": summ[dom]["launches"] / args.steps,
+                    "avg_launch_ms": summ[dom]["ms"] / summ[dom]["launches"],
+                    "avg_launch_gflop": summ[dom]["flops"] / summ[dom]["launches"] / 1e9}
+        out = {
+            "metric": "train images/sec (256x256, whole node)", "value": imgs_per_s, "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "VQ-VAE-GAN train step (D step + G step), num_embeddings=512 embedding_dim=64 "
+                                   f"commitment_cost=0.25, {args.size}x{args.size} RGB, random-init weights",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}"},
+            "step_tflops_necessary": imgs_per_s * GF_PER_IMG_NECESSARY / 1e3 / world,
+            "step_frac_of_bf16_peak": imgs_per_s * GF_PER_IMG_NECESSARY / 1e3 / world / PEAK_BF16_TFLOPS,
+            "losses_finite": finite,
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+            out["cpu_baseline"] = cpu_baseline(2, args.size, threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

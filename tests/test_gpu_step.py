@@ -38,7 +38,7 @@ def test_vq_step_f32_matches_reference():
         for k, v in mine.items():
             ref = float(g[f"it{it}_{k}"])
             tol = max(1e-4, 4 * float(g[f"noise:it{it}_{k}"]))
-            assert abs(float(v) - ref) <= tol * max(abs(ref), 1e-3), (it, k, float(v), ref, tol)
+            assert abs(float(v.detach()) - ref) <= tol * max(abs(ref), 1e-3), (it, k, float(v.detach()), ref, tol)
         match = (idx2.cpu() == as_t(g[f"it{it}_idx2"])).float().mean().item()
         assert match >= (1.0 if it == 0 else float(g["idxeq64:it1_idx2"]) - 0.02), (it, match)
     sd = model.state_dict()
@@ -63,5 +63,5 @@ def test_vq_step_bf16_close_to_reference():
     torch.cuda.synchronize()
     for k, v in {"d_loss": dl["total"], "g_loss": gl["total"], "recon": gl["recon"], "vq": gl["vq"]}.items():
         ref = float(g[f"it0_{k}"])
-        assert abs(float(v) - ref) <= 2e-2 * max(abs(ref), 1e-3), (k, float(v), ref)
+        assert abs(float(v.detach()) - ref) <= 2e-2 * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
     assert all(torch.isfinite(p).all() for p in model.parameters())

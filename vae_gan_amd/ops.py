@@ -30,6 +30,50 @@ def compute_dtype() -> torch.dtype:
     return _COMPUTE_DTYPE[0]
 
 
+class KernelProfile:
+    """Optional per-launch HIP-event timing of the conv kernels (bench.py's live roofline numbers).
+    Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []     # (kernel name, algorithmic flops, start event, end event)
+
+    def launch(self, name, flops, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.records.append((name, flops, e0, e1))
+        return rc
+
+    def summary(self):
+        """name -> dict(launches, flops, ms); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILE = [None]   # set PROFILE[0] = KernelProfile() to time conv launches
+
+
+def _tile_name(npad: int, dt) -> str:
+    t = "bf16" if dt == torch.bfloat16 else "f32"
+    v = "2,2,2,2" if npad % 128 == 0 else ("2,2,4,1" if npad == 64 else "2,1,4,1")
+    return f"igemm_kernel<{t},{v}>"
+
+
+def _conv_flops(d) -> float:
+    return 2.0 * d.n * d.oh * d.ow * d.co * d.ci * d.r * d.s
+
+
+def _timed(name, flops, fn):
+    prof = PROFILE[0]
+    return fn() if prof is None else prof.launch(name, flops, fn)
+
+
 def _npad(n: int) -> int:
     return 32 if n <= 32 else (64 if n <= 64 else (n + 127) // 128 * 128)
 
@@ -148,7 +192,9 @@ def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape) -> torch
     lib = L.load()
     ws = torch.empty(lib.vg_conv_wgrad_ws_bytes(C.byref(desc)) // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
-    L.check(lib.vg_conv_wgrad(C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), L.stream()), "conv_wgrad")
+    L.check(_timed("wgrad(memset+wgrad_kernel+unpack)", _conv_flops(desc),
+                   lambda: lib.vg_conv_wgrad(C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                             L.stream())), "conv_wgrad")
     return dw
 
 
@@ -167,8 +213,10 @@ class Conv2dFn(torch.autograd.Function):
         wp = packs.get(weight, d, 0, dt)
         y = torch.empty(n, d.oh, d.ow, ycs, dtype=dt, device=x.device)
         stats = _stats_buf(_npad(co), x.device) if want_stats else None
-        L.check(L.load().vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(), L.ptr(stats),
-                                     act, 0, L.stream()), "conv_fwd")
+        lib = L.load()
+        L.check(_timed(_tile_name(_npad(co), dt), _conv_flops(d),
+                       lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(),
+                                               L.ptr(stats), act, 0, L.stream())), "conv_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         if want_stats:
@@ -187,8 +235,9 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = ctx.packs.get(weight, d, 1, x.dtype)
             dx = torch.empty_like(x)
-            L.check(lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None, L.ACT_NONE, 0,
-                                      L.stream()), "conv_dgrad")
+            L.check(_timed(_tile_name(_npad(d.ci), x.dtype), _conv_flops(d),
+                           lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
+                                                     L.ACT_NONE, 0, L.stream())), "conv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, x, gy, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -214,8 +263,10 @@ class ConvTranspose2dFn(torch.autograd.Function):
         wpt = packs.get(weight, d, 1, dt)
         y = torch.empty(n, oh, ow, ycs, dtype=dt, device=x.device)
         stats = _stats_buf(_npad(cout_t), x.device) if want_stats else None
-        L.check(L.load().vg_conv_dgrad(C.byref(d), x.data_ptr(), wpt.data_ptr(), L.ptr(bias), y.data_ptr(), L.ptr(stats),
-                                       act, 0, L.stream()), "convT_fwd")
+        lib = L.load()
+        L.check(_timed(_tile_name(_npad(cout_t), dt), _conv_flops(d),
+                       lambda: lib.vg_conv_dgrad(C.byref(d), x.data_ptr(), wpt.data_ptr(), L.ptr(bias), y.data_ptr(),
+                                                 L.ptr(stats), act, 0, L.stream())), "convT_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         if want_stats:
@@ -234,8 +285,9 @@ class ConvTranspose2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wp = ctx.packs.get(weight, d, 0, x.dtype)
             dx = torch.empty_like(x)
-            L.check(lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None, L.ACT_NONE, 0,
-                                    L.stream()), "convT_dgrad")
+            L.check(_timed(_tile_name(_npad(d.co), x.dtype), _conv_flops(d),
+                           lambda: lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None,
+                                                   L.ACT_NONE, 0, L.stream())), "convT_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, gy, x, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
