@@ -68,7 +68,8 @@ int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t,
 size_t vg_conv_wgrad_ws_bytes(const vg_conv_desc* d);
 int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, void* stream);
 
-/* per-channel column sum: out[c] (f32) = sum_m a[m][c], c < c_valid.  bias gradients. */
+/* per-channel column sum: out[c] (f32) = sum_m a[m][c], c < c_valid.  bias gradients.
+ * ws: VG_STATS_REPLICAS*cs f64 of scratch. */
 int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws, void* stream);
 
 /* ---- layout ------------------------------------------------------------------------------ */
@@ -143,22 +144,6 @@ int vg_scalar_finish(const double* src, double scale, float* dst, void* stream);
 /* ---- fused Adam over a flat parameter buffer (<arch>/main.py:34-44, torch.optim.Adam defaults) --- */
 int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, int step, float grad_scale, void* stream);
-
-/* ---- skinny linear (beta_vae_gans/model.py:74-75,87-88,107,139) --------------------------- */
-/* y[b][o] = sum_i x[b][i]*w[o][i] + bias[o]; all f32; weight-streaming (b small). */
-int vg_linear_fwd(const float* x, const float* w, const float* bias, float* y, int b, int in_f, int out_f, void* stream);
-int vg_linear_dgrad(const float* dy, const float* w, float* dx, int b, int in_f, int out_f, void* stream);
-int vg_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, int b, int in_f, int out_f, void* stream);
-
-/* ---- self attention (hierarchical_vae_gan/model.py:24-47) ---------------------------------- */
-/* o[b][i][:] = sum_j softmax_j(q_i.k_j) v[b][j][:]  (no 1/sqrt(d) scale); q,k: [b][hw][dqk_s], v,o: [b][hw][dv_s]
- * NHWC `dtype`; lse: f32 [b][hw] (saved for backward). */
-int vg_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int b, int hw, int dqk, int dqk_s,
-                int dv, int dv_s, int dtype, void* stream);
-int vg_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, void* dq,
-                void* dk, void* dv_out, float* ws, int b, int hw, int dqk, int dqk_s, int dv, int dv_s, int dtype,
-                void* stream);
-size_t vg_attn_bwd_ws_bytes(int b, int hw, int dqk_s, int dv_s);
 
 #ifdef __cplusplus
 }

@@ -158,40 +158,52 @@ extern "C" int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h,
 
 // ---------------------------------------------------------------------------------------------
 // per-channel column sum (bias gradients): out[c] = sum_m a[m][c]
-// thread = one 16-byte piece column; blocks stride over rows; f64 atomics into ws[cs]; finish to f32.
+// thread = one 16-byte piece column over a strided set of rows; the block folds its row groups
+// through LDS and issues ONE f64 atomic per channel into one of VG_STATS_REPLICAS copies.
 // ---------------------------------------------------------------------------------------------
 template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ a, int64_t rows, int cs,
                                                                                 double* __restrict__ ws) {
   constexpr int PIECE = Elt<T>::PIECE;
-  const int ppr = cs / PIECE;                 // pieces per row
-  const int rpb = 256 / ppr > 0 ? 256 / ppr : 1;   // rows per block pass
+  __shared__ float red[256 * PIECE];
+  const int ppr = cs / PIECE;
+  const int rpb = 256 / ppr;
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
-  if (rr >= rpb) return;
   float acc[PIECE];
-#pragma unroll
-  for (int e = 0; e < PIECE; ++e) acc[e] = 0.f;
   double dacc[PIECE];
 #pragma unroll
-  for (int e = 0; e < PIECE; ++e) dacc[e] = 0.0;
-  int cnt = 0;
-  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
-    Piece<T> v;
-    v.v = *(const decltype(v.v)*)(a + (size_t)r * cs + pc * PIECE);
+  for (int e = 0; e < PIECE; ++e) { acc[e] = 0.f; dacc[e] = 0.0; }
+  if (rr < rpb) {
+    int cnt = 0;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+      Piece<T> v;
+      v.v = *(const decltype(v.v)*)(a + (size_t)r * cs + pc * PIECE);
 #pragma unroll
-    for (int e = 0; e < PIECE; ++e) acc[e] += v.get(e);
-    if (++cnt == 64) {
+      for (int e = 0; e < PIECE; ++e) acc[e] += v.get(e);
+      if (++cnt == 64) {
 #pragma unroll
-      for (int e = 0; e < PIECE; ++e) { dacc[e] += acc[e]; acc[e] = 0.f; }
-      cnt = 0;
+        for (int e = 0; e < PIECE; ++e) { dacc[e] += acc[e]; acc[e] = 0.f; }
+        cnt = 0;
+      }
     }
-  }
 #pragma unroll
-  for (int e = 0; e < PIECE; ++e) unsafeAtomicAdd(&ws[pc * PIECE + e], dacc[e] + (double)acc[e]);
+    for (int e = 0; e < PIECE; ++e) red[rr * cs + pc * PIECE + e] = (float)(dacc[e] + (double)acc[e]);
+  }
+  __syncthreads();
+  const int rep = blockIdx.x % VG_STATS_REPLICAS;
+  for (int ch = threadIdx.x; ch < cs; ch += 256) {
+    double t = 0.0;
+    for (int r = 0; r < rpb; ++r) t += red[r * cs + ch];
+    unsafeAtomicAdd(&ws[(size_t)rep * cs + ch], t);
+  }
 }
 
-__global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n, double scale) {
+__global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n, double scale, int replicas,
+                           int stride) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = (float)(src[i] * scale);
+  if (i >= n) return;
+  double t = 0.0;
+  for (int r = 0; r < replicas; ++r) t += src[(size_t)r * stride + i];
+  dst[i] = (float)(t * scale);
 }
 
 extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws,
@@ -200,22 +212,23 @@ extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, 
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_sum: channel stride %d unsupported", cs);
   hipStream_t st = (hipStream_t)stream;
-  VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * cs, st));
+  VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * cs * VG_STATS_REPLICAS, st));
   const int ppr = cs / piece, rpb = 256 / ppr;
-  int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 8);
-  if (blocks > 1024) blocks = 1024;
+  int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 16);
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   if (dtype == VG_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, rows, cs, ws);
   else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws);
   VG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(d2f_kernel, dim3((c_valid + 255) / 256), dim3(256), 0, st, (const double*)ws, out, c_valid, 1.0);
+  hipLaunchKernelGGL(d2f_kernel, dim3((c_valid + 255) / 256), dim3(256), 0, st, (const double*)ws, out, c_valid, 1.0,
+                     VG_STATS_REPLICAS, cs);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
 
 extern "C" int vg_scalar_finish(const double* src, double scale, float* dst, void* stream) {
   VG_REQUIRE(src && dst, "scalar_finish: null pointer");
-  hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, dst, 1, scale);
+  hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, dst, 1, scale, 1, 0);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

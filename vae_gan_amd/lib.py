@@ -65,12 +65,6 @@ SIGNATURES = {
     "vg_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P]),
     "vg_scalar_finish": (_I, [_P, _D, _P, _P]),
     "vg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
-    "vg_linear_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "vg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "vg_linear_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
-    "vg_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "vg_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "vg_attn_bwd_ws_bytes": (C.c_size_t, [_I, _I, _I, _I]),
 }
 
 
@@ -83,8 +77,6 @@ def load() -> C.CDLL:
                                "(there is no CPU fallback for the HIP path)")
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            if os.environ.get("VG_DEV_PARTIAL") == "1" and not hasattr(lib, name):
-                continue               # development only: library built from a subset of the sources
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args

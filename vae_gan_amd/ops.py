@@ -183,7 +183,7 @@ def _channel_sum(t: torch.Tensor, c: int) -> torch.Tensor:
     cs = t.shape[-1]
     rows = t.numel() // cs
     out = torch.empty(c, dtype=torch.float32, device=t.device)
-    ws = torch.empty(cs, dtype=torch.float64, device=t.device)
+    ws = torch.empty(L.STATS_REPLICAS * cs, dtype=torch.float64, device=t.device)
     L.check(L.load().vg_channel_sum(t.data_ptr(), rows, cs, c, L.vg_dtype(t.dtype), out.data_ptr(), ws.data_ptr(), L.stream()), "channel_sum")
     return out
 
