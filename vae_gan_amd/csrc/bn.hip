@@ -45,30 +45,47 @@ extern "C" int vg_bn_finalize(const double* stats, int c, int cpad, int64_t coun
 }
 
 // ---------------------------------------------------------------------------------------------
+// Thread (rr, pc) owns one 16-byte channel piece `pc` for the rows rr, rr+rpb*grid, ...: its PIECE
+// scale/shift coefficients stay in registers, and a wave still touches 1 KiB of contiguous memory.
 template <typename T, bool HAS_RES>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int64_t npieces, int ppr, int c, int act) {
+                                                         int64_t rows, int ppr, int c, int act) {
   constexpr int PIECE = Elt<T>::PIECE;
-  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < npieces; q += (int64_t)gridDim.x * 256) {
-    const int ch0 = (int)(q % ppr) * PIECE;
-    Piece<T> v, r, o;
-    v.v = *(const decltype(v.v)*)(x + q * PIECE);
-    if (HAS_RES) r.v = *(const decltype(r.v)*)(res + q * PIECE);
+  const int rpb = 256 / ppr;
+  const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+  if (rr >= rpb) return;
+  float sc[PIECE], sh[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) {
+    const int ch = pc * PIECE + e;
+    sc[e] = ch < c ? scale[ch] : 0.f;
+    sh[e] = ch < c ? shift[ch] : 0.f;
+  }
+  const size_t cs = (size_t)ppr * PIECE;
+  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+    const size_t off = (size_t)r * cs + pc * PIECE;
+    Piece<T> v, rs, o;
+    v.v = *(const decltype(v.v)*)(x + off);
+    if (HAS_RES) rs.v = *(const decltype(rs.v)*)(res + off);
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) {
-      const int ch = ch0 + e;
-      float f = 0.f;
-      if (ch < c) {
-        f = v.get(e) * scale[ch] + shift[ch];
-        if (HAS_RES) f += r.get(e);
-        if (act == VG_ACT_LRELU) f = vg_lrelu(f);
-        else if (act == VG_ACT_SIGMOID) f = vg_sigmoid(f);
-      }
+      float f = v.get(e) * sc[e] + sh[e];
+      if (HAS_RES) f += rs.get(e);
+      if (act == VG_ACT_LRELU) f = vg_lrelu(f);
+      else if (act == VG_ACT_SIGMOID) f = vg_sigmoid(f);
+      if (pc * PIECE + e >= c) f = 0.f;
       o.set(e, f);
     }
-    *(decltype(o.v)*)(y + q * PIECE) = o.v;
+    *(decltype(o.v)*)(y + off) = o.v;
   }
+}
+
+static int row_blocks(int64_t rows, int rpb, int rows_per_thread) {
+  int64_t b = vg_ceil_div(rows, (int64_t)rpb * rows_per_thread);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
 }
 
 static int ew_blocks(int64_t work_items) {
@@ -82,11 +99,11 @@ extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const floa
                              int cs, int c, int act, int dtype, void* stream) {
   VG_REQUIRE(x && y && scale && shift && rows > 0 && cs >= c, "bn_act_fwd: bad arguments");
   const int piece = dtype == VG_BF16 ? 8 : 4;
-  VG_REQUIRE(cs % piece == 0, "bn_act_fwd: channel stride %d not a multiple of %d", cs, piece);
+  VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "bn_act_fwd: channel stride %d unsupported", cs);
   const int ppr = cs / piece;
-  const int64_t np = rows * ppr;
+  const int64_t np = rows;
   hipStream_t st = (hipStream_t)stream;
-  dim3 g(ew_blocks(np)), b(256);
+  dim3 g(row_blocks(rows, 256 / ppr, 8)), b(256);
   if (dtype == VG_BF16) {
     if (res) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, scale, shift, np, ppr, c, act);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, scale, shift, np, ppr, c, act);
@@ -207,30 +224,41 @@ template <typename T, bool HAS_DRES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
-                                                           T* __restrict__ dx, T* __restrict__ dres, int64_t npieces,
+                                                           T* __restrict__ dx, T* __restrict__ dres, int64_t rows,
                                                            int ppr, int c, int cpad, int act) {
   constexpr int PIECE = Elt<T>::PIECE;
-  for (int64_t q = blockIdx.x * (int64_t)256 + threadIdx.x; q < npieces; q += (int64_t)gridDim.x * 256) {
-    const int ch0 = (int)(q % ppr) * PIECE;
-    Piece<T> g, o, v, rx, rr;
-    g.v = *(const decltype(g.v)*)(dout + q * PIECE);
-    o.v = *(const decltype(o.v)*)(y + q * PIECE);
-    v.v = *(const decltype(v.v)*)(x + q * PIECE);
+  const int rpb = 256 / ppr;
+  const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
+  if (rr >= rpb) return;
+  // d = a*(dz - m1 - xh*m2), xh = (x-mu)*is  ==  a*dz - (a*m1 - a*m2*is*mu) - (a*m2*is)*x
+  float ca[PIECE], cb[PIECE], cx[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) {
+    const int ch = pc * PIECE + e;
+    if (ch < c) {
+      const float a = coef[ch], m1 = coef[cpad + ch], m2 = coef[2 * cpad + ch], mu = mean[ch], is = invstd[ch];
+      ca[e] = a; cx[e] = a * m2 * is; cb[e] = a * m1 - cx[e] * mu;
+    } else {
+      ca[e] = 0.f; cx[e] = 0.f; cb[e] = 0.f;
+    }
+  }
+  const size_t cs = (size_t)ppr * PIECE;
+  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+    const size_t off = (size_t)r * cs + pc * PIECE;
+    Piece<T> g, o, v, rx, rd;
+    g.v = *(const decltype(g.v)*)(dout + off);
+    o.v = *(const decltype(o.v)*)(y + off);
+    v.v = *(const decltype(v.v)*)(x + off);
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) {
-      const int ch = ch0 + e;
-      float dz = 0.f, d = 0.f;
-      if (ch < c) {
-        dz = g.get(e);
-        if (act == VG_ACT_LRELU && !(o.get(e) > 0.f)) dz *= VG_LRELU_SLOPE;
-        const float xh = (v.get(e) - mean[ch]) * invstd[ch];
-        d = coef[ch] * (dz - coef[cpad + ch] - xh * coef[2 * cpad + ch]);
-      }
-      rx.set(e, d);
-      if (HAS_DRES) rr.set(e, dz);
+      float dz = g.get(e);
+      if (act == VG_ACT_LRELU && !(o.get(e) > 0.f)) dz *= VG_LRELU_SLOPE;
+      if (pc * PIECE + e >= c) dz = 0.f;
+      rx.set(e, ca[e] * dz - cb[e] - cx[e] * v.get(e));
+      if (HAS_DRES) rd.set(e, dz);
     }
-    *(decltype(rx.v)*)(dx + q * PIECE) = rx.v;
-    if (HAS_DRES) *(decltype(rr.v)*)(dres + q * PIECE) = rr.v;
+    *(decltype(rx.v)*)(dx + off) = rx.v;
+    if (HAS_DRES) *(decltype(rd.v)*)(dres + off) = rd.v;
   }
 }
 
@@ -239,15 +267,15 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
                                int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream) {
   VG_REQUIRE(dout && y && x && mean && invstd && sums && dx && rows > 0 && cs >= c && cpad >= c, "bn_bwd_apply: bad arguments");
   const int piece = dtype == VG_BF16 ? 8 : 4;
-  VG_REQUIRE(cs % piece == 0, "bn_bwd_apply: channel stride %d unsupported", cs);
+  VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "bn_bwd_apply: channel stride %d unsupported", cs);
   hipStream_t st = (hipStream_t)stream;
   // coefficient scratch lives right behind the f64 sums (caller allocates [REPLICAS*2*cpad] f64 + 3*cpad f32)
   float* coef = (float*)(sums + (size_t)VG_STATS_REPLICAS * 2 * cpad);
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)rows, gamma, invstd, coef, dgamma, dbeta);
   VG_LAUNCH_CHECK();
   const int ppr = cs / piece;
-  const int64_t np = rows * ppr;
-  dim3 g(ew_blocks(np)), b(256);
+  const int64_t np = rows;
+  dim3 g(row_blocks(rows, 256 / ppr, 8)), b(256);
   if (dtype == VG_BF16) {
     if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, coef, (bf16_t*)dx, (bf16_t*)dres, np, ppr, c, cpad, act);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, coef, (bf16_t*)dx, (bf16_t*)nullptr, np, ppr, c, cpad, act);
