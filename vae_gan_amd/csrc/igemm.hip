@@ -50,6 +50,8 @@ template <> struct Mma<float> {
   }
 };
 
+__device__ __attribute__((aligned(64))) const uint32_t vg_zero_block[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
 __device__ __forceinline__ int lds_off64(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -58,6 +60,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// ring depth: as many 64-byte-chunk stages as fit next to a second resident block (<= 80 KiB per block)
+__host__ __device__ constexpr int igemm_stages(int bm, int bn) { return (bm + bn) * 64 * 4 <= 65536 ? 4 : 3; }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 template <typename T, int MI, int NI, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
@@ -65,12 +72,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int AR = BM / 64;                   // A rows staged per thread
   constexpr int BR = (BN + 63) / 64;            // B rows staged per thread (BN=32: threads < 128)
   constexpr int STAGE_A = BM * 64, STAGE_B = BN * 64;
-  constexpr int STAGE = 2 * (STAGE_A + STAGE_B);
+  constexpr int NS = igemm_stages(BM, BN);      // LDS ring depth (chunks resident or in flight)
+  constexpr int STAGE = NS * (STAGE_A + STAGE_B);
   constexpr int TILE = BM * BN * 4;
   constexpr int MAIN = STAGE > TILE ? STAGE : TILE;
+  constexpr int LPC = AR + (BN >= 64 ? BR : 0); // LDS-DMA instructions every wave issues per chunk (lower bound)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
-  unsigned char* sB = smem + 2 * STAGE_A;
+  unsigned char* sB = smem + NS * STAGE_A;
   unsigned* rowpix = (unsigned*)(smem + MAIN);
   float* red = (float*)(smem + MAIN + BM * 4);   // [WM][BN][2]
 
@@ -115,35 +124,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const size_t ktot = (size_t)p.ntaps * p.C;
   const T* __restrict__ wg = (const T*)p.w + ((size_t)phase * p.Npad + n0) * ktot;
 
-  u32x4 ra[AR], rb[BR];
+  // Global -> LDS staging uses LDS-DMA (global_load_lds_dwordx4): one wave instruction writes 1 KiB
+  // = 16 rows x 64 B linearly, so thread (srow, sslot) lands at physical slot sslot of its row and
+  // must FETCH the logical slot sslot ^ ((row>>2)&3) (swizzle applied on the source address).
+  // Padding / out-of-range rows read a 64-byte zero block instead.
+  const int lslot = (sslot ^ (srow >> 2)) & 3;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
   int tap = 0, cc = 0;   // position of the NEXT chunk to load
-  auto load_chunk = [&]() {
+  auto load_chunk = [&](int buf) {
     const int dy = p.dy[phase][tap], dx = p.dx[phase][tap];
-    const int coff = cc * KC + sslot * PIECE;
+    const int coff = cc * KC + lslot * PIECE;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
       bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *(const u32x4*)(xg + ((size_t)(a_nh[i] + iy) * p.W + ix) * p.Cs + coff);
-      ra[i] = v;
+      const void* src = ok ? (const void*)(xg + ((size_t)(a_nh[i] + iy) * p.W + ix) * p.Cs + coff) : (const void*)vg_zero_block;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (lds_ptr_t)(sA + buf * STAGE_A + (wave * 16 + 64 * i) * 64), 16, 0, 0);
     }
     const size_t koff = (size_t)tap * p.C + coff;
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
       int r = srow + 64 * i;
-      if (BN >= 64 || r < BN) rb[i] = *(const u32x4*)(wg + (size_t)r * ktot + koff);
+      if (BN >= 64 || wave < 2)   // BN == 32: only rows 0..31 exist (waves 0 and 1), wave-uniform branch
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (size_t)r * ktot + koff),
+                                         (lds_ptr_t)(sB + buf * STAGE_B + (wave * 16 + 64 * i) * 64), 16, 0, 0);
     }
     if (++cc == cchunks) { cc = 0; ++tap; }
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AR; ++i) *(u32x4*)(sA + buf * STAGE_A + lds_off64(srow + 64 * i, sslot)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      int r = srow + 64 * i;
-      if (BN >= 64 || r < BN) *(u32x4*)(sB + buf * STAGE_B + lds_off64(r, sslot)) = rb[i];
-    }
   };
 
   f32x16 acc[MI][NI];
@@ -154,14 +161,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_chunk();
-  store_chunk(0);
-  __syncthreads();
+  // Ring pipeline: chunks ks .. ks+NS-2 are in flight or resident; the DMA for chunk ks+NS-1 is issued
+  // right after the barrier of step ks into the buffer every wave finished reading in step ks-1.
+  // Waits are counted (never drained inside the steady state) and the barrier is a raw s_barrier so the
+  // outstanding LDS-DMA stays in flight across it.
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nk) load_chunk(s0);
+  int rbuf = 0, wbuf = NS - 1;
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) load_chunk();
-    const unsigned char* cA = sA + buf * STAGE_A;
-    const unsigned char* cB = sB + buf * STAGE_B;
+    if (ks + NS - 2 < nk) wait_vmcnt<(NS - 2) * LPC>();   // chunk ks landed (this wave's share)
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ks + NS - 1 < nk) load_chunk(wbuf);
+    const unsigned char* cA = sA + rbuf * STAGE_A;
+    const unsigned char* cB = sB + rbuf * STAGE_B;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       u32x4 fa[MI], fb[NI];
@@ -174,9 +189,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int jj = 0; jj < NI; ++jj) acc[i][jj] = Mma<T>::run(fa[i], fb[jj], acc[i][jj]);
     }
-    if (ks + 1 < nk) store_chunk(buf ^ 1);
-    __syncthreads();
+    rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
+    wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
   }
+  __syncthreads();   // all fragment reads done before the epilogue tile aliases the ring
 
   // ---- epilogue: bias, stats (on dtype-rounded pre-activation), activation, LDS-staged stores
   float* tile = (float*)smem;   // [BM][BN] f32, aliases the staging buffers (all reads done: synced)
@@ -248,7 +264,7 @@ template <typename T, int MI, int NI, int WM, int WN>
 static int launch_igemm(const IgemmParams& p0, hipStream_t st) {
   IgemmParams p = p0;
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
-  constexpr int STAGE = 2 * (BM * 64 + BN * 64), TILE = BM * BN * 4;
+  constexpr int STAGE = igemm_stages(BM, BN) * (BM * 64 + BN * 64), TILE = BM * BN * 4;
   constexpr int MAIN = STAGE > TILE ? STAGE : TILE;
   const size_t lds = MAIN + BM * 4 + WM * BN * 2 * 4;
   p.mtiles = (int)vg_ceil_div(p.M, BM);
