@@ -58,6 +58,13 @@ int vg_conv_pack_weight(const vg_conv_desc* d, int transposed, const float* w_oi
  * and nn.ConvTranspose2d's input-gradient. */
 int vg_conv_fwd(const vg_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
                 double* stats, int act, int accumulate, void* stream);
+/* Same result as vg_conv_fwd (no stats / accumulate) for shapes with few output tiles and a long reduction:
+ * the K loop is cut into `ksplit` slices (<=0: chosen by the library) whose f32 partial sums meet in `ws`
+ * (vg_conv_splitk_ws_bytes(d) bytes).  Carries the Linear layers of beta_vae_gans/model.py:74-75,87-88,107,139
+ * (a Linear over [B,F] is a 1x1 conv over an NHWC [B,1,1,F] tensor; an f32 [out][in] weight IS its packed image). */
+size_t vg_conv_splitk_ws_bytes(const vg_conv_desc* d);
+int vg_conv_fwd_splitk(const vg_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                       int act, int ksplit, void* ws, void* stream);
 /* dx = act(convT(dy, W) + bias) [+ dx]: the conv's input gradient, and nn.ConvTranspose2d's forward
  * (vq_vae_gan/model.py:186; beta_vae_gans/model.py:123).  w_packed is the transposed image. */
 int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
@@ -76,6 +83,10 @@ int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, 
 /* NCHW f32 [n][c][h][w]  <->  NHWC `dtype` [n][h][w][cs] (channels >= c written as zero). */
 int vg_nchw_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int cs, int dtype, void* stream);
 int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h, int w, int cs, int dtype, void* stream);
+
+/* dst[p][y][x] = mean of the 2x2 block of src (NCHW f32, `planes` = n*c): the 'area' reconstruction target of the
+ * documented non-reference shim D1 (the beta decoder emits 128x128, beta_vae_gans/model.py:104,121-126). */
+int vg_avgpool2_nchw(const float* src, float* dst, int64_t planes, int h, int w, void* stream);
 
 /* ---- BatchNorm (training mode) + LeakyReLU(0.2) + residual ---------------------------------- */
 /* From the f64 stats of vg_conv_fwd: mean/invstd (biased var, eps), affine scale/shift, and the
@@ -138,6 +149,11 @@ int vg_reparam_kl_fwd(const float* mu, const float* logvar, const float* eps, in
 /* dmu = gz + (*gkl)*ckl*(-2mu)... see kernel; gradients of z and of the KL sum w.r.t. mu/logvar. */
 int vg_reparam_kl_bwd(const float* mu, const float* logvar, const float* eps, const float* gz, const float* gkl,
                       float ckl, int64_t n, float* dmu, float* dlogvar, void* stream);
+/* out[c] = sum_r a[r][c] for a row-major f32 [rows][cols] matrix with few rows (Linear bias gradients). */
+int vg_colsum_f32(const float* a, int rows, int64_t cols, float* out, void* stream);
+/* torch.clamp(x, lo, hi) (beta_vae_gans/model.py:91, hierarchical_vae_gan/model.py:168).  g == NULL: forward
+ * y = clamp(x); g != NULL: backward y = g where lo <= x <= hi, else 0. */
+int vg_clamp(const float* x, const float* g, float lo, float hi, float* y, int64_t n, void* stream);
 /* f64 scalar -> f32 scalar with scale: dst[0] = (float)(src[0]*scale). */
 int vg_scalar_finish(const double* src, double scale, float* dst, void* stream);
 

@@ -27,6 +27,8 @@ struct IgemmParams {
   int in_s, out_s;     // gather stride, scatter stride
   int ntaps, nphases;
   int act, accumulate;
+  int ksplit;          // >1: grid.z slices of the K loop; raw f32 partials go to splitws by atomics
+  float* splitws;      // [pixels][Npad] f32, zeroed by the launcher
   int M;               // N*OHl*OWl
   int mtiles, ntiles;
   signed char dy[VG_MAX_PHASES][VG_MAX_TAPS];
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   const T* __restrict__ xg = (const T*)p.x;
   const int cchunks = p.C / KC;
-  const int nk = p.ntaps * cchunks;
+  const int nk_all = p.ntaps * cchunks;
+  const int kbeg = (int)((long)nk_all * blockIdx.z / p.ksplit), kend = (int)((long)nk_all * (blockIdx.z + 1) / p.ksplit);
+  const int nk = kend - kbeg;
   const size_t ktot = (size_t)p.ntaps * p.C;
   const T* __restrict__ wg = (const T*)p.w + ((size_t)phase * p.Npad + n0) * ktot;
 
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // Padding / out-of-range rows read a 64-byte zero block instead.
   const int lslot = (sslot ^ (srow >> 2)) & 3;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  int tap = 0, cc = 0;   // position of the NEXT chunk to load
+  int tap = kbeg / cchunks, cc = kbeg - tap * cchunks;   // position of the NEXT chunk to load
   auto load_chunk = [&](int buf) {
     const int dy = p.dy[phase][tap], dx = p.dx[phase][tap];
     const int coff = cc * KC + lslot * PIECE;
@@ -193,6 +197,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
   }
   __syncthreads();   // all fragment reads done before the epilogue tile aliases the ring
+
+  if (p.ksplit > 1) {
+    // split-K: add this slice's raw partial sums into the f32 workspace (bias/activation happen in the
+    // finish kernel); one lane half covers 32 consecutive channels = one 128-byte segment per row
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + (wn * NI + j) * 32 + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned pix = rowpix[(wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+          if (pix != 0xFFFFFFFFu) unsafeAtomicAdd(&p.splitws[(size_t)pix * p.Npad + n], acc[i][j][r]);
+        }
+      }
+    return;
+  }
 
   // ---- epilogue: bias, stats (on dtype-rounded pre-activation), activation, LDS-staged stores
   float* tile = (float*)smem;   // [BM][BN] f32, aliases the staging buffers (all reads done: synced)
@@ -275,7 +296,7 @@ static int launch_igemm(const IgemmParams& p0, hipStream_t st) {
     VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid(p.mtiles * p.ntiles, p.nphases);
+  dim3 grid(p.mtiles * p.ntiles, p.nphases, p.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -346,11 +367,77 @@ extern "C" int vg_conv_fwd(const vg_conv_desc* d, const void* x, const void* w_p
   p.OHl = d->oh; p.OWl = d->ow; p.OH = d->oh; p.OW = d->ow; p.Ks = d->ycs;
   p.Nout = d->co; p.Npad = vg_npad(d->co);
   p.in_s = d->stride; p.out_s = 1; p.ntaps = d->r * d->s; p.nphases = 1;
-  p.act = act; p.accumulate = accumulate;
+  p.act = act; p.accumulate = accumulate; p.ksplit = 1;
   p.M = d->n * d->oh * d->ow;
   for (int r = 0; r < d->r; ++r)
     for (int s = 0; s < d->s; ++s) { p.dy[0][r * d->s + s] = (signed char)(r - d->pad); p.dx[0][r * d->s + s] = (signed char)(s - d->pad); }
   return d->dtype == VG_BF16 ? dispatch_igemm<bf16_t>(p, (hipStream_t)stream) : dispatch_igemm<float>(p, (hipStream_t)stream);
+}
+
+// ---- split-K forward: few output tiles but a long reduction (Linear layers viewed as 1x1 convs over
+// [B,1,1,F] tensors, the PatchGAN tail).  Partials are summed in an f32 workspace, then finished.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                            T* __restrict__ y, long pixels, int Npad, int Ks, int Nout, int act) {
+  const long total = pixels * Ks;
+  for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const long pix = t / Ks;
+    const int n = (int)(t - pix * Ks);
+    float v = 0.f;
+    if (n < Nout) {
+      v = ws[pix * Npad + n] + (bias ? bias[n] : 0.f);
+      v = Elt<T>::to_f(Elt<T>::from_f(v));
+      if (act == VG_ACT_LRELU) v = vg_lrelu(v);
+      else if (act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
+    }
+    y[t] = Elt<T>::from_f(v);
+  }
+}
+
+extern "C" size_t vg_conv_splitk_ws_bytes(const vg_conv_desc* d) {
+  if (!d) return 0;
+  return (size_t)d->n * d->oh * d->ow * vg_npad(d->co) * sizeof(float);
+}
+
+extern "C" int vg_conv_fwd_splitk(const vg_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                                  int act, int ksplit, void* ws, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  VG_REQUIRE(x && w_packed && y && ws, "conv_fwd_splitk: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w_packed; p.bias = nullptr; p.y = y; p.stats = nullptr;
+  p.N = d->n; p.H = d->h; p.W = d->w; p.C = cpad_of(d->ci, d->dtype); p.Cs = d->xcs;
+  p.OHl = d->oh; p.OWl = d->ow; p.OH = d->oh; p.OW = d->ow; p.Ks = d->ycs;
+  p.Nout = d->co; p.Npad = vg_npad(d->co);
+  p.in_s = d->stride; p.out_s = 1; p.ntaps = d->r * d->s; p.nphases = 1;
+  p.M = d->n * d->oh * d->ow;
+  for (int r = 0; r < d->r; ++r)
+    for (int s = 0; s < d->s; ++s) { p.dy[0][r * d->s + s] = (signed char)(r - d->pad); p.dx[0][r * d->s + s] = (signed char)(s - d->pad); }
+  const int nk = p.ntaps * (p.C / kc_of(d->dtype));
+  if (ksplit <= 0) {   // heuristic: enough blocks for ~2 per CU, at least 8 K-chunks per slice
+    const long tiles = vg_ceil_div(p.M, p.Npad % 128 == 0 ? 128 : 256) * (p.Npad % 128 == 0 ? p.Npad / 128 : 1);
+    ksplit = (int)vg_ceil_div(512, tiles);
+  }
+  if (ksplit > nk / 8) ksplit = nk / 8;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > 65535) ksplit = 65535;
+  p.ksplit = ksplit; p.splitws = (float*)ws; p.act = VG_ACT_NONE;
+  if (ksplit == 1) {
+    p.bias = bias; p.act = act;
+    return d->dtype == VG_BF16 ? dispatch_igemm<bf16_t>(p, st) : dispatch_igemm<float>(p, st);
+  }
+  VG_HIP(hipMemsetAsync(ws, 0, vg_conv_splitk_ws_bytes(d), st));
+  rc = d->dtype == VG_BF16 ? dispatch_igemm<bf16_t>(p, st) : dispatch_igemm<float>(p, st);
+  if (rc) return rc;
+  const long total = (long)p.M * p.Ks;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (d->dtype == VG_BF16) hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const float*)ws, bias, (bf16_t*)y, (long)p.M, p.Npad, p.Ks, p.Nout, act);
+  else hipLaunchKernelGGL(splitk_finish_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)ws, bias, (float*)y, (long)p.M, p.Npad, p.Ks, p.Nout, act);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
 }
 
 extern "C" int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
@@ -367,7 +454,7 @@ extern "C" int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* 
   p.OHl = d->h / s; p.OWl = d->w / s; p.OH = d->h; p.OW = d->w; p.Ks = d->xcs;
   p.Nout = d->ci; p.Npad = vg_npad(d->ci);
   p.in_s = 1; p.out_s = s; p.nphases = s * s;
-  p.act = act; p.accumulate = accumulate;
+  p.act = act; p.accumulate = accumulate; p.ksplit = 1;
   p.M = d->n * p.OHl * p.OWl;
   int nt = -1;
   for (int ph = 0; ph < s * s; ++ph) {

@@ -218,3 +218,41 @@ extern "C" int vg_adam_step(float* p, const float* g, float* m, float* v, int64_
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+// ---- column sums of a small-row f32 matrix (Linear bias gradients): out[c] = sum_r a[r][c] -------------
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ a, int rows, int64_t cols,
+                                                         float* __restrict__ out) {
+  for (int64_t c = blockIdx.x * (int64_t)256 + threadIdx.x; c < cols; c += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += a[(size_t)r * cols + c];
+    out[c] = s;
+  }
+}
+
+extern "C" int vg_colsum_f32(const float* a, int rows, int64_t cols, float* out, void* stream) {
+  VG_REQUIRE(a && out && rows > 0 && cols > 0, "colsum_f32: bad arguments");
+  int64_t blocks = (cols + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, rows, cols, out);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---- clamp (torch.clamp(logvar, -20, 20): beta_vae_gans/model.py:91, hierarchical_vae_gan/model.py:168) ----
+// forward: y = min(max(x, lo), hi); backward (g != null): y = (lo <= x <= hi) ? g : 0
+__global__ __launch_bounds__(256) void clamp_kernel(const float* __restrict__ x, const float* __restrict__ g, float lo, float hi,
+                                                    float* __restrict__ y, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = x[i];
+    y[i] = g ? ((v >= lo && v <= hi) ? g[i] : 0.f) : fminf(fmaxf(v, lo), hi);
+  }
+}
+
+extern "C" int vg_clamp(const float* x, const float* g, float lo, float hi, float* y, int64_t n, void* stream) {
+  VG_REQUIRE(x && y && n > 0 && lo <= hi, "clamp: bad arguments");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(clamp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, g, lo, hi, y, n);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -232,3 +232,29 @@ extern "C" int vg_scalar_finish(const double* src, double scale, float* dst, voi
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+// 2x2 average pooling of an NCHW f32 tensor (the non-reference 'area' target of shim D1: the beta decoder
+// emits 128x128 for a 256x256 input, beta_vae_gans/model.py:104,121-126)
+__global__ __launch_bounds__(256) void avgpool2_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t planes,
+                                                       int h, int w) {
+  const int oh = h / 2, ow = w / 2;
+  const int64_t total = planes * oh * ow;
+  for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(t % ow);
+    const int64_t r = t / ow;
+    const int oy = (int)(r % oh);
+    const int64_t pl = r / oh;
+    const float* s = src + (pl * h + 2 * oy) * w + 2 * ox;
+    dst[t] = 0.25f * ((s[0] + s[1]) + (s[w] + s[w + 1]));
+  }
+}
+
+extern "C" int vg_avgpool2_nchw(const float* src, float* dst, int64_t planes, int h, int w, void* stream) {
+  VG_REQUIRE(src && dst && planes > 0 && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0, "avgpool2: bad arguments");
+  int64_t total = planes * (h / 2) * (w / 2);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, planes, h, w);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -40,12 +40,15 @@ SIGNATURES = {
     "vg_conv_packed_bytes": (C.c_size_t, [_DP, _I]),
     "vg_conv_pack_weight": (_I, [_DP, _I, _P, _P, _P]),
     "vg_conv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vg_conv_splitk_ws_bytes": (C.c_size_t, [_DP]),
+    "vg_conv_fwd_splitk": (_I, [_DP, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vg_conv_dgrad": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vg_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
     "vg_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _P]),
     "vg_channel_sum": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
     "vg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "vg_avgpool2_nchw": (_I, [_P, _P, _L, _I, _I, _P]),
     "vg_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vg_channel_stats": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
@@ -63,6 +66,8 @@ SIGNATURES = {
     "vg_reduce_f32_bwd": (_I, [_P, _P, _F, _L, _I, _P, _P]),
     "vg_reparam_kl_fwd": (_I, [_P, _P, _P, _L, _P, _P, _P]),
     "vg_reparam_kl_bwd": (_I, [_P, _P, _P, _P, _P, _F, _L, _P, _P, _P]),
+    "vg_colsum_f32": (_I, [_P, _I, _L, _P, _P]),
+    "vg_clamp": (_I, [_P, _P, _F, _F, _P, _L, _P]),
     "vg_scalar_finish": (_I, [_P, _D, _P, _P]),
     "vg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
 }

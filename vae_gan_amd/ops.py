@@ -561,3 +561,100 @@ def reparameterize(mu, logvar, eps):
 
 def kl_divergence(mu, logvar):
     return KLFn.apply(mu, logvar)
+
+
+# ----------------------------------------------------------------------------------------------
+# Linear (beta_vae_gans/model.py:74-75,107): a 1x1 conv over an NHWC [B,1,1,F] f32 tensor
+# ----------------------------------------------------------------------------------------------
+def _lin_desc(rows, cin, cout, xcs=None, ycs=None):
+    dt = torch.float32
+    return L.ConvDesc(n=rows, h=1, w=1, oh=1, ow=1, ci=cin, co=cout, xcs=xcs or L.pad_channels(cin, dt),
+                      ycs=ycs or L.pad_channels(cout, dt), r=1, s=1, stride=1, pad=0, dtype=L.VG_F32)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b in f32 on the exact-f32 MFMA.  The row-major [out][in] master weight is its own packed
+    image, so nothing is repacked: forward = split-K igemm (weight streamed once), input gradient and weight
+    gradient = the pixel-reduction (wgrad) kernel with the roles of the operands chosen so that both are read
+    in their natural row-major layout."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_cuda(x, "linear")
+        lib = L.load()
+        x = x.contiguous().float()
+        b, fin = x.shape
+        fout = weight.shape[0]
+        if fin % 16 or fout % 16:
+            raise RuntimeError("linear: feature counts must be multiples of 16")
+        d = _lin_desc(b, fin, fout)
+        y = torch.empty(b, fout, dtype=torch.float32, device=x.device)
+        ws = torch.empty(lib.vg_conv_splitk_ws_bytes(C.byref(d)) // 4, dtype=torch.float32, device=x.device)
+        L.check(lib.vg_conv_fwd_splitk(C.byref(d), x.data_ptr(), weight.data_ptr(), L.ptr(bias), y.data_ptr(), L.ACT_NONE, 0,
+                                       ws.data_ptr(), L.stream()), "linear_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        gy = gy.contiguous().float()
+        b, fin = x.shape
+        fout = weight.shape[0]
+        bp = L.pad_channels(b, torch.float32)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[b][k] = sum_o gy[b][o] W[o][k]: "pixels" = o; dy := gy^T [o][bp], x := W [o][fin]
+            gyt = torch.empty(fout, bp, dtype=torch.float32, device=x.device)
+            L.check(lib.vg_nchw_to_nhwc(gy.data_ptr(), gyt.data_ptr(), 1, b, 1, fout, bp, L.VG_F32, L.stream()), "linear.gyT")
+            d2 = L.ConvDesc(n=1, h=1, w=fout, oh=1, ow=fout, ci=fin, co=b, xcs=fin, ycs=bp, r=1, s=1, stride=1, pad=0,
+                            dtype=L.VG_F32)
+            dx = _wgrad(d2, weight, gyt, (b, fin))
+        if ctx.needs_input_grad[1]:
+            # dW[o][k] = sum_b gy[b][o] x[b][k]: "pixels" = b
+            d = _lin_desc(b, fin, fout)
+            dw = _wgrad(d, x, gy, (fout, fin))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(fout, dtype=torch.float32, device=x.device)
+            L.check(lib.vg_colsum_f32(gy.data_ptr(), b, fout, db.data_ptr(), L.stream()), "linear.dbias")
+        return dx, dw, db
+
+
+def linear(x, weight, bias):
+    return LinearFn.apply(x, weight, bias)
+
+
+class ClampFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        _require_cuda(x, "clamp")
+        x = x.contiguous().float()
+        y = torch.empty_like(x)
+        L.check(L.load().vg_clamp(x.data_ptr(), None, lo, hi, y.data_ptr(), x.numel(), L.stream()), "clamp")
+        ctx.save_for_backward(x)
+        ctx.lo, ctx.hi = lo, hi
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        L.check(L.load().vg_clamp(x.data_ptr(), g.contiguous().float().data_ptr(), ctx.lo, ctx.hi, dx.data_ptr(), x.numel(),
+                                  L.stream()), "clamp_bwd")
+        return dx, None, None
+
+
+def clamp(x, lo, hi):
+    return ClampFn.apply(x, float(lo), float(hi))
+
+
+def avg_pool2(x: torch.Tensor) -> torch.Tensor:
+    """2x2 area downsample of an NCHW f32 tensor (no gradient: used on the target image only)."""
+    _require_cuda(x, "avg_pool2")
+    x = x.detach().contiguous().float()
+    n, c, h, w = x.shape
+    out = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device)
+    L.check(L.load().vg_avgpool2_nchw(x.data_ptr(), out.data_ptr(), n * c, h, w, L.stream()), "avgpool2")
+    return out

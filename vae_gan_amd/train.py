@@ -83,3 +83,24 @@ def vq_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[
         g_loss['total'].backward()
     opt_g.step(dp.reduce(opt_g) if dp else 1.0)
     return d_loss, g_loss, indices
+
+
+def beta_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[DataParallel] = None, eps=None,
+                    elide_d_wgrad: bool = True):
+    """beta_vae_gans/main.py:75-108: ONE generator forward per iteration; the G step reuses recon/mu/logvar and
+    only re-runs D(recon).  With the reference's shapes loss_function raises (128 vs 256) unless the model was
+    built with recon_target_policy='area' (shim D1)."""
+    opt_d.zero_grad()
+    recon, _, mu, logvar = model(images, eps)
+    disc_real = model.discriminator(images)
+    disc_fake = model.discriminator(recon.detach())
+    d_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=False)
+    d_loss['total'].backward()
+    opt_d.step(dp.reduce(opt_d) if dp else 1.0)
+    opt_g.zero_grad()
+    with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
+        disc_fake = model.discriminator(recon)
+        g_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=True)
+        g_loss['total'].backward()
+    opt_g.step(dp.reduce(opt_g) if dp else 1.0)
+    return d_loss, g_loss
