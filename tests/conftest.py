@@ -59,6 +59,10 @@ def check_digests(g, grads, rtol=2e-4, k=4.0, name_map=lambda n: n):
     mathematically-zero gradient (fp noise on every implementation): for those
     only require 'tiny relative to the sibling weight gradient'."""
     n = 0
+    # module-level reproducibility floor: one parameter's recorded noise is a single sample (a LeakyReLU sign flip
+    # may or may not have hit it), so never go below the median noise of the module's parameters
+    ns = [float(v) for kk, v in g.items() if kk.startswith("noise:gd:") and float(v) < 1.0]
+    floor = float(np.median(ns)) if ns else 0.0
     for key, ref in g.items():
         if not key.startswith("gd:"):
             continue
@@ -71,7 +75,7 @@ def check_digests(g, grads, rtol=2e-4, k=4.0, name_map=lambda n: n):
         if sib is not None and ref[0] < 1e-4 * sib[0]:
             assert mine[0] < 1e-3 * sib[0], f"{name}: expected ~0 grad, l2 {mine[0]:.3e} (weight l2 {sib[0]:.3e})"
             continue
-        tol = max(rtol, k * float(g.get("noise:" + key, 0.0)))
+        tol = max(rtol, k * max(float(g.get("noise:" + key, 0.0)), floor))
         assert abs(mine[0] - ref[0]) <= tol * l2, f"{name}: l2 {mine[0]:.6e} vs {ref[0]:.6e} (tol {tol:.1e})"
         assert abs(mine[2] - ref[2]) <= 4 * tol * l2, f"{name}: probe {mine[2]:.6e} vs {ref[2]:.6e} (tol {tol:.1e})"
         n += 1
