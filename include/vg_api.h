@@ -161,6 +161,22 @@ int vg_scalar_finish(const double* src, double scale, float* dst, void* stream);
 int vg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                  float eps, int step, float grad_scale, void* stream);
 
+/* ---- spatial self attention (hierarchical_vae_gan/model.py:24-47) ---------------------------------- */
+/* o[b][i][:] = sum_j softmax_j(q_i . k_j) v[b][j][:] with NO 1/sqrt(d) scale (model.py:37-42).  All f32, NHWC-flat:
+ * q,k [b][hw][d], v,o [b][hw][c]; lse [b][hw] (log-sum-exp per query, kept for the backward).  hw % 32 == 0,
+ * d even <= 32, c in {32,64,128,256}.  The [hw,hw] matrix is never materialised. */
+int vg_attn_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int b, int hw, int d, int c,
+                void* stream);
+/* Gradients of the above w.r.t. q, k, v given d_o; delta_ws: b*hw f32 of scratch. */
+int vg_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                float* dq, float* dk, float* dv, float* delta_ws, int b, int hw, int d, int c, void* stream);
+/* y = gamma[0]*o + x (model.py:45); backward: d_o = gamma*gy, dgamma[0] (f64, zeroed by caller) += sum gy*o. */
+int vg_gamma_residual(const float* o, const float* x, const float* gamma, float* y, int64_t n, void* stream);
+int vg_gamma_residual_bwd(const float* gy, const float* o, const float* gamma, float* d_o, double* dgamma, int64_t n,
+                          void* stream);
+/* elementwise storage cast bf16 <-> f32 (n % 8 == 0). */
+int vg_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,6 +69,11 @@ SIGNATURES = {
     "vg_colsum_f32": (_I, [_P, _I, _L, _P, _P]),
     "vg_clamp": (_I, [_P, _P, _F, _F, _P, _L, _P]),
     "vg_scalar_finish": (_I, [_P, _D, _P, _P]),
+    "vg_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vg_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vg_gamma_residual": (_I, [_P, _P, _P, _P, _L, _P]),
+    "vg_gamma_residual_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
+    "vg_cast": (_I, [_P, _P, _L, _I, _I, _P]),
     "vg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
 }
 

@@ -658,3 +658,69 @@ def avg_pool2(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty(n, c, h // 2, w // 2, dtype=torch.float32, device=x.device)
     L.check(L.load().vg_avgpool2_nchw(x.data_ptr(), out.data_ptr(), n * c, h, w, L.stream()), "avgpool2")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# self attention (hierarchical_vae_gan/model.py:24-47)
+# ----------------------------------------------------------------------------------------------
+def _to_f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype == torch.float32:
+        return t.contiguous()
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    L.check(L.load().vg_cast(t.data_ptr(), out.data_ptr(), t.numel(), L.VG_BF16, L.VG_F32, L.stream()), "cast")
+    return out
+
+
+def _from_f32(t: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    if dt == torch.float32:
+        return t
+    out = torch.empty(t.shape, dtype=dt, device=t.device)
+    L.check(L.load().vg_cast(t.contiguous().data_ptr(), out.data_ptr(), t.numel(), L.VG_F32, L.VG_BF16, L.stream()), "cast")
+    return out
+
+
+class AttentionFn(torch.autograd.Function):
+    """out = gamma * softmax(q k^T) v + x on NHWC tensors [B,H,W,*] (q,k: [..,dqk_s], v,x: [..,cs])."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, x, gamma):
+        _require_cuda(q, "attention")
+        lib = L.load()
+        dt = x.dtype
+        b, hh, ww, cs = v.shape
+        hw, d = hh * ww, q.shape[-1]
+        qf, kf, vf, xf = _to_f32(q), _to_f32(k), _to_f32(v), _to_f32(x)
+        o = torch.empty_like(vf)
+        lse = torch.empty(b * hw, dtype=torch.float32, device=q.device)
+        L.check(lib.vg_attn_fwd(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), o.data_ptr(), lse.data_ptr(), b, hw, d, cs,
+                                L.stream()), "attn_fwd")
+        y = torch.empty_like(vf)
+        gam = gamma.detach().float().contiguous()
+        L.check(lib.vg_gamma_residual(o.data_ptr(), xf.data_ptr(), gam.data_ptr(), y.data_ptr(), y.numel(), L.stream()), "gamma_residual")
+        ctx.save_for_backward(qf, kf, vf, o, lse, gam)
+        ctx.dt, ctx.dims = dt, (b, hw, d, cs)
+        return _from_f32(y, dt)
+
+    @staticmethod
+    def backward(ctx, gy):
+        qf, kf, vf, o, lse, gam = ctx.saved_tensors
+        lib = L.load()
+        b, hw, d, cs = ctx.dims
+        gyf = _to_f32(gy)
+        d_o = torch.empty_like(o)
+        dgam = torch.zeros(1, dtype=torch.float64, device=o.device)
+        L.check(lib.vg_gamma_residual_bwd(gyf.data_ptr(), o.data_ptr(), gam.data_ptr(), d_o.data_ptr(), dgam.data_ptr(),
+                                          o.numel(), L.stream()), "gamma_residual_bwd")
+        dq, dk, dv = torch.empty_like(qf), torch.empty_like(kf), torch.empty_like(vf)
+        ws = torch.empty(b * hw, dtype=torch.float32, device=o.device)
+        L.check(lib.vg_attn_bwd(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+                                dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), b, hw, d, cs, L.stream()), "attn_bwd")
+        dgamma = torch.empty(1, dtype=torch.float32, device=o.device)
+        L.check(lib.vg_scalar_finish(dgam.data_ptr(), 1.0, dgamma.data_ptr(), L.stream()), "dgamma")
+        dt = ctx.dt
+        return _from_f32(dq, dt), _from_f32(dk, dt), _from_f32(dv, dt), _from_f32(gyf, dt) if dt != torch.float32 else gyf, dgamma
+
+
+def attention(q, k, v, x, gamma):
+    return AttentionFn.apply(q, k, v, x, gamma)

@@ -104,3 +104,25 @@ def beta_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optiona
         g_loss['total'].backward()
     opt_g.step(dp.reduce(opt_g) if dp else 1.0)
     return d_loss, g_loss
+
+
+def hier_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[DataParallel] = None, eps_lists=(None, None),
+                    elide_d_wgrad: bool = True):
+    """hierarchical_vae_gan/main.py:75-111: two generator forwards per iteration (fresh N(0,1) draws for each of the
+    three levels in both).  Needs hier_decoder_policy='nearest' + recon_target_policy='area' (shims D2 + D1): with the
+    reference's own composition the decoder raises."""
+    opt_d.zero_grad()
+    recon, _, mu_list, logvar_list = model(images, eps_lists[0])
+    disc_real = model.discriminator(images)
+    disc_fake = model.discriminator(recon.detach())
+    d_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=False)
+    d_loss['total'].backward()
+    opt_d.step(dp.reduce(opt_d) if dp else 1.0)
+    opt_g.zero_grad()
+    recon, _, mu_list, logvar_list = model(images, eps_lists[1])
+    with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
+        disc_fake = model.discriminator(recon)
+        g_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=True)
+        g_loss['total'].backward()
+    opt_g.step(dp.reduce(opt_g) if dp else 1.0)
+    return d_loss, g_loss
