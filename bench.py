@@ -142,7 +142,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-            out["cpu_baseline"] = cpu_baseline(2, args.size, threads)
+            out["cpu_baseline"] = cpu_baseline(16, args.size, threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
