@@ -43,6 +43,10 @@ typedef struct {
   int dtype;          /* VG_F32 | VG_BF16                                        */
 } vg_conv_desc;
 
+/* Development/ablation switch: 1 = im2col-row implicit GEMM only, anything else = spatial-tile (halo) kernel
+ * where it applies (default). */
+void vg_set_conv_kernel(int version);
+
 /* ---- weight packing ---------------------------------------------------------------------- */
 /* Bytes of the packed forward (transposed=0) or dgrad (transposed=1) weight image. */
 size_t vg_conv_packed_bytes(const vg_conv_desc* d, int transposed);

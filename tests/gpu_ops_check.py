@@ -106,6 +106,13 @@ CASES = [
     (1, 16, 16, 128, 256, 4, 2, 1),
     (1, 8, 8, 320, 128, 3, 1, 1),     # hierarchical decoder concat width
     (1, 8, 8, 256, 512, 3, 1, 1),
+    # wide rows: the ping-pong spatial-tile kernel (>= 24 px wide, >= 4 taps, stride-1 gather)
+    (2, 40, 36, 64, 64, 3, 1, 1),     # 64-channel config, ragged tiles
+    (1, 33, 65, 96, 128, 3, 1, 1),    # 128-channel config, 3 chunks, 3 tile columns
+    (1, 20, 32, 128, 256, 3, 1, 1),   # 256-channel config
+    (1, 32, 32, 64, 256, 4, 1, 1),    # 4x4 stride-1 (discriminator tail), 31x31 output
+    (1, 64, 64, 64, 128, 4, 2, 1),    # dgrad = 4 phases of 2x2 taps, 64-channel config with 3 halo buffers
+    (1, 64, 64, 128, 64, 4, 2, 1),    # dgrad with 128 output channels
 ]
 
 if __name__ == "__main__":

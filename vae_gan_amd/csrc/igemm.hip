@@ -11,6 +11,11 @@
 // the ds_write_b128 staging stores and the ds_read_b128 fragment loads bank-conflict free.
 #include "common.h"
 
+#ifdef VG_ABLATE   // timing ablations only (results are wrong): see tests/gpu_conv_ablate.py
+#define VG_DBG(bit) (p.dbg & (bit))
+#else
+#define VG_DBG(bit) false
+#endif
 #define VG_MAX_PHASES 4
 #define VG_MAX_TAPS 16
 
@@ -33,7 +38,30 @@ struct IgemmParams {
   int mtiles, ntiles;
   signed char dy[VG_MAX_PHASES][VG_MAX_TAPS];
   signed char dx[VG_MAX_PHASES][VG_MAX_TAPS];
+  // spatial-tile ("halo") kernel only
+  int tilesX, tilesY, HH, HWd, nsh;
+  int flip;               // igemm3: tap offsets descend (input gradients, transposed gathers)
+  int dbg;             // timing ablations only (wrong results): 1 = no in-loop DMA, 2 = no barrier/wait, 4 = no LDS fragment reads
+  signed char dymin[VG_MAX_PHASES], dxmin[VG_MAX_PHASES];
+  // tap offsets again, 4 bits per tap biased by 8: the kernels index them with scalar shifts.  (A dynamic
+  // index into the byte tables above compiles to a vector load + s_waitcnt vmcnt(0), which drains the
+  // LDS-DMA ring on every step.)
+  unsigned long long dyp[VG_MAX_PHASES], dxp[VG_MAX_PHASES];
+  int dymin_i[VG_MAX_PHASES], dxmin_i[VG_MAX_PHASES];
 };
+
+static void pack_taps(IgemmParams& p) {
+  for (int ph = 0; ph < VG_MAX_PHASES; ++ph) {
+    unsigned long long a = 0, b = 0;
+    for (int t = 0; t < VG_MAX_TAPS; ++t) {
+      a |= (unsigned long long)((p.dy[ph][t] + 8) & 15) << (4 * t);
+      b |= (unsigned long long)((p.dx[ph][t] + 8) & 15) << (4 * t);
+    }
+    p.dyp[ph] = a; p.dxp[ph] = b;
+    p.dymin_i[ph] = p.dymin[ph]; p.dxmin_i[ph] = p.dxmin[ph];
+  }
+}
+__device__ __forceinline__ int tap_off(unsigned long long pack, int tap) { return (int)((pack >> (4 * tap)) & 15) - 8; }
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -135,8 +163,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int lslot = (sslot ^ (srow >> 2)) & 3;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   int tap = kbeg / cchunks, cc = kbeg - tap * cchunks;   // position of the NEXT chunk to load
+  const unsigned long long dyp = p.dyp[phase], dxp = p.dxp[phase];
   auto load_chunk = [&](int buf) {
-    const int dy = p.dy[phase][tap], dx = p.dx[phase][tap];
+    const int dy = tap_off(dyp, tap), dx = tap_off(dxp, tap);
     const int coff = cc * KC + lslot * PIECE;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -297,12 +326,680 @@ static int launch_igemm(const IgemmParams& p0, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(p.mtiles * p.ntiles, p.nphases, p.ksplit);
+  pack_taps(p);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
 
+// =============================================================================================
+// igemm2: spatial-tile kernel.  A block owns TH x 16 output pixels of ONE image.  For every 64-byte
+// channel chunk the input patch that all taps need (the tile plus its halo) is brought into LDS ONCE by
+// LDS-DMA; the R*S taps then read their shifted A fragments from that patch, so the L2->LDS traffic of the
+// activations drops by ~R*S (9x for 3x3, 4x for the stride-2 4x4) compared with the im2col-row kernel
+// above, which was bound by that traffic (~30 B/clk/CU), not by MFMA.  Weights stream through a 4-deep
+// ring (one tap-chunk per step) with counted vmcnt waits and raw s_barrier, as above.
+// =============================================================================================
+template <typename T, int MI, int NI, int WM, int WN, int TH>
+__global__ __launch_bounds__(64 * WM * WN) void igemm2_kernel(const IgemmParams p) {
+  constexpr int NT = 64 * WM * WN, TW = 16, BM = TH * TW, BN = 32 * NI * WN;
+  static_assert(BM == 32 * MI * WM, "tile / wave layout mismatch");
+  constexpr int EB = sizeof(T), KC = 64 / EB, PIECE = 16 / EB;
+  constexpr int NSB = 4, PF = NSB - 1;
+  constexpr int BSTRIDE = (BN >= 64 ? BN : 64) * 64;             // BN == 32: rows 32..63 are a dummy target (uniform vmcnt)
+  constexpr int LPB = (BSTRIDE / 16) / NT;                       // B DMA instructions per wave per step
+  static_assert(LPB >= 1, "every wave must issue at least one weight DMA per step");
+  constexpr int MAXROWS = TH == 16 ? 19 * 19 : 18 * 34;
+  constexpr int HRMAX = (MAXROWS * 4 + NT - 1) / NT;
+  constexpr int WTILE = 32 * MI * 32 * NI * EB;                  // per-wave epilogue staging bytes
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int hrows = p.HH * p.HWd;
+  const int hbytes = ((hrows + 15) & ~15) * 64;
+  unsigned char* sH = smem;                                      // [nsh][hbytes]
+  unsigned char* sB = smem + p.nsh * hbytes;                     // [NSB][BSTRIDE]
+  const int pipe_bytes = p.nsh * hbytes + NSB * BSTRIDE;
+  const int main_bytes = pipe_bytes > WM * WN * WTILE ? pipe_bytes : WM * WN * WTILE;
+  unsigned* rowpix = (unsigned*)(smem + main_bytes);
+  float* red = (float*)(smem + main_bytes + BM * 4);             // [WM][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, l32 = lane & 31;
+  const int lid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
+  const int phase = blockIdx.y;
+  const int py = phase / p.out_s, px = phase % p.out_s;
+  const int n0 = ntile * BN;
+  const int tpi = p.tilesX * p.tilesY;
+  const int img = mtile / tpi;
+  const int trem = mtile - img * tpi;
+  const int ty0 = (trem / p.tilesX) * TH, tx0 = (trem % p.tilesX) * TW;
+  const int dymin = p.dymin_i[phase], dxmin = p.dxmin_i[phase];
+  const unsigned long long dyp = p.dyp[phase], dxp = p.dxp[phase];
+  const int swz = p.in_s == 2 ? 1 : 2;                            // halo-row swizzle: slot ^= (row >> swz) & 3
+
+  for (int r = tid; r < BM; r += NT) {
+    const int oy = ty0 + r / TW, ox = tx0 + r % TW;
+    unsigned v = 0xFFFFFFFFu;
+    if (oy < p.OHl && ox < p.OWl) v = (unsigned)((img * p.OH + oy * p.out_s + py) * p.OW + ox * p.out_s + px);
+    rowpix[r] = v;
+  }
+
+  // ---- halo pieces owned by this thread: 16-byte piece q = round*NT + tid -> halo row q>>2, physical slot q&3
+  const T* __restrict__ xg = (const T*)p.x;
+  unsigned poff[HRMAX];     // source offset in 16-byte units (chunk 0), 0xFFFFFFFF = zero fill
+  const int iy_base = ty0 * p.in_s + dymin, ix_base = tx0 * p.in_s + dxmin;
+#pragma unroll
+  for (int rd = 0; rd < HRMAX; ++rd) {
+    const int q = rd * NT + tid;
+    const int hr = q >> 2, ps = q & 3;
+    unsigned o = 0xFFFFFFFFu;
+    if (hr < hrows) {
+      const int hy = hr / p.HWd, hx = hr - hy * p.HWd;
+      const int iy = iy_base + hy, ix = ix_base + hx;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+        const int ls = (ps ^ (hr >> swz)) & 3;
+        o = (unsigned)((((size_t)(img * p.H + iy) * p.W + ix) * p.Cs * EB) >> 4) + ls;
+      }
+    }
+    poff[rd] = o;
+  }
+  const int cchunks = p.C / KC;
+  const int nk = p.ntaps * cchunks;
+  const size_t ktot = (size_t)p.ntaps * p.C;
+  const T* __restrict__ wg = (const T*)p.w + ((size_t)phase * p.Npad + n0) * ktot;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+
+  int itap = 0, icc = 0, ihb = 0, ibb = 0;     // issue cursor: tap, chunk, halo buffer, B buffer
+  auto issue = [&]() {
+    if (itap == 0) {
+      unsigned char* dst = sH + ihb * hbytes;
+#pragma unroll
+      for (int rd = 0; rd < HRMAX; ++rd) {
+        const int q0w = rd * NT + wave * 64;                    // first piece of this wave in this round (uniform)
+        if (q0w < hrows * 4) {
+          const int q = q0w + lane;
+          if (q < hrows * 4) {
+            const unsigned char* src = poff[rd] == 0xFFFFFFFFu ? (const unsigned char*)vg_zero_block
+                                                                : (const unsigned char*)xg + ((size_t)poff[rd] << 4) + (size_t)icc * 64;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(dst + q0w * 16), 16, 0, 0);
+          }
+        }
+      }
+      ihb = ihb + 1 == p.nsh ? 0 : ihb + 1;
+    }
+    {
+      const size_t koff = (size_t)itap * p.C + (size_t)icc * KC;
+      unsigned char* dst = sB + ibb * BSTRIDE;
+#pragma unroll
+      for (int i = 0; i < LPB; ++i) {
+        const int q = i * NT + tid;                             // piece of the [rows][64 B] weight chunk
+        int row = q >> 2;
+        const int ps = q & 3;
+        if (BN < 64) row &= (BN - 1);                           // dummy rows re-read real ones
+        const int ls = (ps ^ (row >> 2)) & 3;
+        __builtin_amdgcn_global_load_lds((gptr_t)(wg + (size_t)row * ktot + koff + ls * PIECE),
+                                         (lds_ptr_t)(dst + (i * NT + wave * 64) * 16), 16, 0, 0);
+      }
+      ibb = ibb + 1 == NSB ? 0 : ibb + 1;
+    }
+    if (++itap == p.ntaps) { itap = 0; ++icc; }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // halo row of this lane's pixel for each A block (tap offset added per step)
+  int arow[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int pr = (wm * MI + i) * 32 + l32;
+    arow[i] = (pr / TW) * p.in_s * p.HWd + (pr % TW) * p.in_s;
+  }
+
+#pragma unroll
+  for (int s0 = 0; s0 < PF; ++s0)
+    if (s0 < nk) issue();
+  int ctap = 0, chb = 0, cbb = 0;              // compute cursor
+  for (int s = 0; s < nk; ++s) {
+    if (!VG_DBG(2)) {
+      if (s + PF - 1 < nk) wait_vmcnt<(PF - 1) * LPB>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("" ::: "memory");
+    if (s + PF < nk && !VG_DBG(1)) issue();
+    const unsigned char* cH = sH + chb * hbytes;
+    const unsigned char* cB = sB + cbb * BSTRIDE;
+    const int toff = (tap_off(dyp, ctap) - dymin) * p.HWd + (tap_off(dxp, ctap) - dxmin);
+    int abase[MI], aswz[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = arow[i] + toff;
+      abase[i] = row * 64;
+      aswz[i] = (row >> swz) & 3;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      u32x4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *(const u32x4*)(cH + (VG_DBG(4) ? 0 : abase[i] + ((((2 * j + h) ^ aswz[i]) & 3) << 4)));
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fb[i] = *(const u32x4*)(cB + (VG_DBG(4) ? 0 : lds_off64((wn * NI + i) * 32 + l32, 2 * j + h)));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NI; ++jj) acc[i][jj] = Mma<T>::run(fa[i], fb[jj], acc[i][jj]);
+    }
+    cbb = cbb + 1 == NSB ? 0 : cbb + 1;
+    if (++ctap == p.ntaps) { ctap = 0; chb = chb + 1 == p.nsh ? 0 : chb + 1; }
+  }
+  __syncthreads();   // every fragment read is done before the staging area aliases the rings
+
+  // ---- epilogue: bias, BN statistics, activation; each wave stages its own sub-tile in T and stores 16 B pieces
+  T* wt = (T*)(smem + wave * WTILE);            // [32*MI][32*NI]
+  constexpr int WN_COLS = 32 * NI;
+  float s1[NI], s2[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + (wn * NI + j) * 32 + l32;
+    const float bv = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[i][j][r] + bv;
+        v = Elt<T>::to_f(Elt<T>::from_f(v));
+        if (rowpix[wm * MI * 32 + lrow] != 0xFFFFFFFFu) { a1 += v; a2 += v * v; }
+        if (p.act == VG_ACT_LRELU) v = vg_lrelu(v);
+        else if (p.act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
+        if (n >= p.Nout) v = 0.f;
+        wt[lrow * WN_COLS + j * 32 + l32] = Elt<T>::from_f(v);
+      }
+    }
+    s1[j] = a1 + __shfl_xor(a1, 32, 64);
+    s2[j] = a2 + __shfl_xor(a2, 32, 64);
+  }
+  if (p.stats != nullptr && h == 0) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = (wn * NI + j) * 32 + l32;
+      red[(wm * BN + col) * 2 + 0] = s1[j];
+      red[(wm * BN + col) * 2 + 1] = s2[j];
+    }
+  }
+  __syncthreads();
+  if (p.stats != nullptr && tid < BN && n0 + tid < p.Nout) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+    const int rep = (mtile + phase) % VG_STATS_REPLICAS;
+    unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.Npad + n0 + tid], (double)t1);
+    unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + n0 + tid], (double)t2);
+  }
+  T* __restrict__ yg = (T*)p.y;
+  constexpr int PPR = WN_COLS / PIECE;
+  for (int q = lane; q < 32 * MI * PPR; q += 64) {
+    const int lrow = q / PPR, pc = q - lrow * PPR;
+    const unsigned pix = rowpix[wm * MI * 32 + lrow];
+    const int n = n0 + wn * WN_COLS + pc * PIECE;
+    if (pix == 0xFFFFFFFFu || n >= p.Ks) continue;
+    Piece<T> o;
+    o.v = *(const decltype(o.v)*)(wt + lrow * WN_COLS + pc * PIECE);
+    T* dst = yg + (size_t)pix * p.Ks + n;
+    if (p.accumulate) {
+      Piece<T> old;
+      old.v = *(const decltype(old.v)*)dst;
+#pragma unroll
+      for (int e = 0; e < PIECE; ++e) o.set(e, o.get(e) + old.get(e));
+    }
+    *(decltype(o.v)*)dst = o.v;
+  }
+}
+
+static int g_dbg = 0;   // timing ablations (vg_set_conv_kernel bits 8+)
+template <typename T, int MI, int NI, int WM, int WN, int TH>
+static int launch_igemm2(const IgemmParams& p0, hipStream_t st, bool* handled) {
+  IgemmParams p = p0;
+  constexpr int NT = 64 * WM * WN, BM = TH * 16, BN = 32 * NI * WN, EB = sizeof(T);
+  constexpr int NSB = 4, PF = NSB - 1;
+  constexpr int BSTRIDE = (BN >= 64 ? BN : 64) * 64;
+  constexpr int MAXROWS = TH == 16 ? 19 * 19 : 18 * 34;
+  constexpr int WTILE = 32 * MI * 32 * NI * EB;
+  *handled = false;
+  int ext_y = 0, ext_x = 0;
+  for (int ph = 0; ph < p.nphases; ++ph) {
+    int ymin = 127, ymax = -127, xmin = 127, xmax = -127;
+    for (int t = 0; t < p.ntaps; ++t) {
+      ymin = p.dy[ph][t] < ymin ? p.dy[ph][t] : ymin; ymax = p.dy[ph][t] > ymax ? p.dy[ph][t] : ymax;
+      xmin = p.dx[ph][t] < xmin ? p.dx[ph][t] : xmin; xmax = p.dx[ph][t] > xmax ? p.dx[ph][t] : xmax;
+    }
+    p.dymin[ph] = (signed char)ymin; p.dxmin[ph] = (signed char)xmin;
+    ext_y = ymax - ymin > ext_y ? ymax - ymin : ext_y;
+    ext_x = xmax - xmin > ext_x ? xmax - xmin : ext_x;
+  }
+  p.HH = (TH - 1) * p.in_s + ext_y + 1;
+  p.HWd = (16 - 1) * p.in_s + ext_x + 1;
+  const int hrows = p.HH * p.HWd;
+  if (hrows > MAXROWS) return VG_OK;          // not handled: caller falls back to the im2col-row kernel
+  p.nsh = 1 + (PF + p.ntaps - 1) / p.ntaps;
+  const int hbytes = ((hrows + 15) & ~15) * 64;
+  const int pipe = p.nsh * hbytes + NSB * BSTRIDE;
+  const int mainb = pipe > WM * WN * WTILE ? pipe : WM * WN * WTILE;
+  const size_t lds = (size_t)mainb + BM * 4 + WM * BN * 2 * 4;
+  if (lds > 160 * 1024) return VG_OK;
+  p.dbg = g_dbg;
+  p.tilesX = (int)vg_ceil_div(p.OWl, 16);
+  p.tilesY = (int)vg_ceil_div(p.OHl, TH);
+  p.mtiles = p.N * p.tilesX * p.tilesY;
+  p.ntiles = p.Npad / BN;
+  auto kern = igemm2_kernel<T, MI, NI, WM, WN, TH>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  pack_taps(p);
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.nphases), dim3(NT), lds, st, p);
+  VG_LAUNCH_CHECK();
+  *handled = true;
+  return VG_OK;
+}
+
+
+// =============================================================================================
+// igemm3: ping-pong spatial-tile kernel for stride-1 gathers with a static R x S tap grid (3x3 and 4x4
+// convs and their input gradients, the 2x2-tap phases of stride-2 transposed gathers) whose output rows
+// are at least 24 pixels wide.  bf16 only (the f32 parity mode keeps the kernels above).
+//
+// Block = 8 waves = two groups of four (one wave of each group per SIMD) over a TH x 32 pixel tile of one
+// image and BN output channels; a wave owns a (32*MI) x (32*NI) accumulator.  The two groups run one
+// barrier apart: while one issues the 8 MFMA blocks of a phase, the other reads its next fragments
+// from LDS and issues its share of the LDS-DMA prefetch (the 2-barriers-per-phase schedule of the guide's
+// 256^2 GEMM template, applied to the halo gather).  A wave issues at most one instruction per ~4 cycles,
+// so the memory part of a phase only hides behind the other group's 256 MFMA cycles if it is ~50
+// instructions: the tap loop is fully unrolled (tap geometry, halo round and prefetch tap are compile-time),
+// the halo image uses a fixed 35-pixel row stride with the 16-byte slot XOR-swizzled by the COLUMN
+// (so a tap shift is one scalar offset and the 32-row blocks of a wave are immediates), out-of-image
+// halo pieces are zeroed once and masked off in every DMA, and all counted vmcnt waits are constants.
+//
+// Weights stream through a 5-slot ring three K tiles ahead.  The halo of channel chunk cc+1 rides on
+// the prefetch slots of chunk cc.  A wait keeps the two youngest weight tiles in flight; halo pieces
+// among them only make it wait for slightly more (never less) than needed.
+// =============================================================================================
+template <typename T, int MI, int NI, int WM, int WN, int R, int S>
+struct Igemm3Cfg {
+  static constexpr int NT = 512, TW = 32, TH = MI * WM, BM = TH * TW, BN = 32 * NI * WN;
+  static constexpr int EB = sizeof(T), KC = 64 / EB, PIECE = 16 / EB;
+  static constexpr int NTAPS = R * S, PF = 3, NSB = PF + 2;
+  static constexpr int NPH = (MI * NI == 8) ? 2 : 1;          // phases per K tile, 8 MFMA blocks each
+  static constexpr int KPP = 2 / NPH;                         // 16-byte fragment steps per phase
+  static constexpr int BSTRIDE = BN * 64;
+  static constexpr int LPB = (BN * 4 + NT - 1) / NT;          // weight DMA instructions per wave per K tile
+  static constexpr int BLANES = BN * 4 >= NT ? 64 : BN * 4 / 8;   // active lanes of one (BN = 64: half-masked)
+  static constexpr int HS = 35, HSB = HS * 64, HH = TH + R - 1;   // halo image: HH rows of 35 pixels x 64 B
+  static constexpr int HRN = (HH * HS * 4 + NT - 1) / NT;     // DMA rounds (512 x 16 B) per halo image
+  static constexpr int HBYTES = HRN * NT * 16;
+  static constexpr int NSH = NTAPS >= PF + 1 + HRN ? 2 : 3;   // halo buffers
+  static constexpr int HSTART = NSH == 2 ? PF + 1 : 0;        // first prefetch tap that carries a halo round
+  static constexpr int WTILE = 32 * 32 * NI * EB;             // per-wave epilogue staging: one 32-row block
+  static constexpr int PIPE = NSH * HBYTES + NSB * BSTRIDE;
+  static constexpr int MAINB = PIPE > 8 * WTILE ? PIPE : 8 * WTILE;
+  static constexpr int LDS = MAINB + BM * 4 + WM * BN * 2 * 4;
+  static constexpr bool FITS = LDS <= 160 * 1024 && (NSH == 2 || HRN <= 2 * NTAPS);
+};
+
+template <typename T, int MI, int NI, int WM, int WN, int R, int S>
+__global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
+  typedef Igemm3Cfg<T, MI, NI, WM, WN, R, S> Cfg;
+  static_assert(WM * WN == 8, "two groups of four waves");
+  constexpr int NT = Cfg::NT, TW = Cfg::TW, TH = Cfg::TH, BM = Cfg::BM, BN = Cfg::BN;
+  constexpr int EB = Cfg::EB, KC = Cfg::KC, PIECE = Cfg::PIECE;
+  constexpr int NTAPS = Cfg::NTAPS, PF = Cfg::PF, NSB = Cfg::NSB, NPH = Cfg::NPH, KPP = Cfg::KPP;
+  constexpr int BSTRIDE = Cfg::BSTRIDE, LPB = Cfg::LPB, BLANES = Cfg::BLANES;
+  constexpr int HS = Cfg::HS, HSB = Cfg::HSB, HH = Cfg::HH, HRN = Cfg::HRN, HBYTES = Cfg::HBYTES, NSH = Cfg::NSH;
+  constexpr int HSTART = Cfg::HSTART, WTILE = Cfg::WTILE;
+  constexpr int SB_OFF = NSH * HBYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* rowpix = (unsigned*)(smem + Cfg::MAINB);
+  float* red = (float*)(smem + Cfg::MAINB + BM * 4);   // [WM][BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: everything derived from it stays scalar
+  const int group = wave >> 2;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, l32 = lane & 31;
+  const int lid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+  const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
+  const int phase = blockIdx.y;
+  const int py = phase / p.out_s, px = phase % p.out_s;
+  const int n0 = ntile * BN;
+  const int tpi = p.tilesX * p.tilesY;
+  const int img = mtile / tpi;
+  const int trem = mtile - img * tpi;
+  const int ty0 = (trem / p.tilesX) * TH, tx0 = (trem % p.tilesX) * TW;
+  const int dymin = p.dymin_i[phase], dxmin = p.dxmin_i[phase];
+  const bool flip = p.flip != 0;       // taps run high-to-low offsets (input gradients, transposed gathers)
+
+  for (int r = tid; r < BM; r += NT) {
+    const int oy = ty0 + r / TW, ox = tx0 + r % TW;
+    unsigned v = 0xFFFFFFFFu;
+    if (oy < p.OHl && ox < p.OWl) v = (unsigned)((img * p.OH + oy * p.out_s + py) * p.OW + ox * p.out_s + px);
+    rowpix[r] = v;
+  }
+
+  // ---- halo pieces of this thread: 16-byte piece q = round*NT + tid -> halo pixel q>>2 = hy*35 + hx, physical slot q&3.
+  // Pieces outside the image are zeroed here in every halo buffer and never written again.
+  const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
+  unsigned poff[HRN];       // byte offset of the piece in channel chunk 0, 0xFFFFFFFF = not fetched
+  const int iy_base = ty0 + dymin, ix_base = tx0 + dxmin;
+#pragma unroll
+  for (int rd = 0; rd < HRN; ++rd) {
+    const int q = rd * NT + tid;
+    const int pix = q >> 2, ps = q & 3;
+    const int hy = pix / HS, hx = pix - hy * HS;
+    const int iy = iy_base + hy, ix = ix_base + hx;
+    unsigned o = 0xFFFFFFFFu;
+    if (hy < HH && hx < TW + S - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      o = (unsigned)((((size_t)(img * p.H + iy) * p.W + ix) * p.Cs) * EB) + (((ps ^ (hx >> 2)) & 3) << 4);
+    poff[rd] = o;
+    if (o == 0xFFFFFFFFu) {
+#pragma unroll
+      for (int b = 0; b < NSH; ++b) *(u32x4*)(smem + b * HBYTES + q * 16) = u32x4{0, 0, 0, 0};
+    }
+  }
+  const int cchunks = p.C / KC;
+  const size_t ktot = (size_t)NTAPS * p.C;
+  const unsigned char* __restrict__ wg = (const unsigned char*)((const T*)p.w + ((size_t)phase * p.Npad + n0) * ktot);
+  const int cbytes = p.C * EB;          // one tap of one weight row
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+
+  unsigned boff[LPB];       // weight piece of this thread: byte offset inside the [BN][ktot] slab
+#pragma unroll
+  for (int i = 0; i < LPB; ++i) {
+    const int q = i * NT + wave * BLANES + (lane & (BLANES - 1));
+    const int row = q >> 2, ps = q & 3;
+    boff[i] = (unsigned)((row * ktot + (((ps ^ (row >> 2)) & 3) * PIECE)) * EB);
+  }
+  // fragment addresses: A = ct[s] + scalar(tile), +i*HSB per 32-row block, ^32 for the second k step;
+  // B = bfo + scalar(slot), +2048 per 32-column block, ^32 likewise
+  int ct[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int hx = l32 + (flip ? S - 1 - s : s);
+    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4);
+  }
+  const int bfo = lds_off64(wn * NI * 32 + l32, h) + SB_OFF;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- DMA helpers; tap / round arguments are compile-time after unrolling
+  auto dma_b = [&](int i, int itap, int icc, int slot) {
+    const unsigned char* src = wg + ((size_t)itap * cbytes + (size_t)icc * 64) + boff[i];
+    unsigned char* dst = smem + SB_OFF + slot * BSTRIDE + (i * NT + wave * BLANES) * 16;
+    if (BLANES == 64 || lane < BLANES) __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+  };
+  auto dma_h = [&](int rd, int icc, int hboff) {
+    if (poff[rd] != 0xFFFFFFFFu)
+      __builtin_amdgcn_global_load_lds((gptr_t)(xg + (size_t)icc * 64 + poff[rd]),
+                                       (lds_ptr_t)(smem + hboff + (rd * NT + wave * 64) * 16), 16, 0, 0);
+  };
+  // halo rounds of chunk icc that ride on the prefetch slot of tap itap
+  auto halo_rounds = [&](int itap, int icc, int hboff) {
+    if (icc < cchunks) {
+#pragma unroll
+      for (int rd = 0; rd < HRN; ++rd)
+        if (NSH == 2 ? rd == itap - HSTART : rd % NTAPS == itap) dma_h(rd, icc, hboff);
+    }
+  };
+
+  // ---- prologue: halo of chunk 0, weights (and attached halo rounds of chunk 1) of the first PF tiles
+#pragma unroll
+  for (int rd = 0; rd < HRN; ++rd) dma_h(rd, 0, 0);
+#pragma unroll
+  for (int t0 = 0; t0 < PF; ++t0) {
+#pragma unroll
+    for (int i = 0; i < LPB; ++i) dma_b(i, t0, 0, t0);
+    halo_rounds(t0, 1, NSH > 1 ? HBYTES : 0);
+  }
+  __syncthreads();                                   // drains the prologue DMA once; zero fill and rowpix visible
+  if (group == 1 && !VG_DBG(2)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
+
+  int cbs = 0;                         // weight slot of the tile being computed
+  int hb0 = 0;                         // halo buffer offset of the chunk being computed
+  for (int cc = 0; cc < cchunks; ++cc) {
+    const int hb1 = hb0 + HBYTES == NSH * HBYTES ? 0 : hb0 + HBYTES;     // chunk cc+1
+    const int hb2 = hb1 + HBYTES == NSH * HBYTES ? 0 : hb1 + HBYTES;     // chunk cc+2
+    const int wcc = cc + 1 < cchunks ? cc + 1 : 0;   // weights prefetched past the end re-read chunk 0 (never consumed)
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int r = tap / S, s = tap % S;
+      const int itap = (tap + PF) % NTAPS;           // tile the prefetch of this step belongs to
+      const bool wrap = tap + PF >= NTAPS;
+      const int ibs = cbs + PF >= NSB ? cbs + PF - NSB : cbs + PF;
+      const int va0 = ct[s] + hb0 + (wm * MI + (flip ? R - 1 - r : r)) * HSB;
+      const int vb0 = bfo + cbs * BSTRIDE;
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+        u32x4 fa[KPP][MI], fb[KPP][NI];
+        // ---- memory part: fragments of this phase, DMA prefetch, retire the next tile's DMA
+#pragma unroll
+        for (int kk = 0; kk < KPP; ++kk) {
+          const int j = ph * KPP + kk;
+          const int va = VG_DBG(4) ? 0 : (j ? va0 ^ 32 : va0), vb = VG_DBG(4) ? 0 : (j ? vb0 ^ 32 : vb0);
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[kk][i] = *(const u32x4*)(smem + va + i * HSB);
+#pragma unroll
+          for (int jj = 0; jj < NI; ++jj) fb[kk][jj] = *(const u32x4*)(smem + vb + jj * 2048);
+        }
+        if (!VG_DBG(1)) {
+#pragma unroll
+          for (int i = 0; i < LPB; ++i)
+            if (i % NPH == ph) dma_b(i, itap, wrap ? wcc : cc, ibs);
+          if (ph == NPH - 1) halo_rounds(itap, wrap ? cc + 2 : cc + 1, wrap ? hb2 : hb1);
+        }
+        if (ph == NPH - 1 && !VG_DBG(2)) wait_vmcnt<(PF - 1) * LPB>();
+        if (!VG_DBG(2)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < KPP; ++kk)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) acc[i][jj] = Mma<T>::run(fa[kk][i], fb[kk][jj], acc[i][jj]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!VG_DBG(2)) __builtin_amdgcn_s_barrier();
+      }
+      cbs = cbs + 1 == NSB ? 0 : cbs + 1;
+    }
+    hb0 = hb1;
+  }
+  if (group == 0 && !VG_DBG(2)) __builtin_amdgcn_s_barrier();     // both groups have now passed the same number of barriers
+  wait_vmcnt<0>();   // weight tiles prefetched past the end
+  __syncthreads();   // every fragment read is done before the staging area aliases the rings
+
+  // ---- epilogue: bias, BN statistics, activation; each wave stages one 32-row block at a time in T
+  T* wt = (T*)(smem + wave * WTILE);            // [32][32*NI]
+  constexpr int WN_COLS = 32 * NI;
+  constexpr int PPR = WN_COLS / PIECE;
+  T* __restrict__ yg = (T*)p.y;
+  float bv[NI], a1[NI], a2[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + (wn * NI + j) * 32 + l32;
+    bv[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
+    a1[j] = a2[j] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const unsigned* rp = rowpix + (wm * MI + i) * 32;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + (wn * NI + j) * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[i][j][r] + bv[j];
+        v = Elt<T>::to_f(Elt<T>::from_f(v));
+        if (rp[lrow] != 0xFFFFFFFFu) { a1[j] += v; a2[j] += v * v; }
+        if (p.act == VG_ACT_LRELU) v = vg_lrelu(v);
+        else if (p.act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
+        if (n >= p.Nout) v = 0.f;
+        wt[lrow * WN_COLS + j * 32 + l32] = Elt<T>::from_f(v);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int q = lane; q < 32 * PPR; q += 64) {
+      const int lrow = q / PPR, pc = q - lrow * PPR;
+      const unsigned pix = rp[lrow];
+      const int n = n0 + wn * WN_COLS + pc * PIECE;
+      if (pix == 0xFFFFFFFFu || n >= p.Ks) continue;
+      Piece<T> o;
+      o.v = *(const decltype(o.v)*)(wt + lrow * WN_COLS + pc * PIECE);
+      T* dst = yg + (size_t)pix * p.Ks + n;
+      if (p.accumulate) {
+        Piece<T> old;
+        old.v = *(const decltype(old.v)*)dst;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) o.set(e, o.get(e) + old.get(e));
+      }
+      *(decltype(o.v)*)dst = o.v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (p.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float s1 = a1[j] + __shfl_xor(a1[j], 32, 64), s2 = a2[j] + __shfl_xor(a2[j], 32, 64);
+      if (h == 0) {
+        const int col = (wn * NI + j) * 32 + l32;
+        red[(wm * BN + col) * 2 + 0] = s1;
+        red[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Nout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+      const int rep = (mtile + phase) % VG_STATS_REPLICAS;
+      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.Npad + n0 + tid], (double)t1);
+      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + n0 + tid], (double)t2);
+    }
+  }
+}
+
+template <typename T, int MI, int NI, int WM, int WN, int R, int S>
+static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
+  typedef Igemm3Cfg<T, MI, NI, WM, WN, R, S> Cfg;
+  *handled = false;
+  if constexpr (Cfg::FITS) {
+    IgemmParams p = p0;
+    // the tap grid must be R x S, row-major, offsets all ascending or all descending, the same in every phase
+    int flip = -1;
+    for (int ph = 0; ph < p.nphases; ++ph) {
+      int ymin = 127, xmin = 127;
+      for (int t = 0; t < p.ntaps; ++t) {
+        ymin = p.dy[ph][t] < ymin ? p.dy[ph][t] : ymin;
+        xmin = p.dx[ph][t] < xmin ? p.dx[ph][t] : xmin;
+      }
+      p.dymin[ph] = (signed char)ymin; p.dxmin[ph] = (signed char)xmin;
+      bool asc = true, desc = true;
+      for (int t = 0; t < p.ntaps; ++t) {
+        const int yo = p.dy[ph][t] - ymin, xo = p.dx[ph][t] - xmin;
+        asc = asc && yo == t / S && xo == t % S;
+        desc = desc && yo == R - 1 - t / S && xo == S - 1 - t % S;
+      }
+      const int f = asc ? 0 : (desc ? 1 : -2);
+      if (f < 0 || (flip >= 0 && f != flip)) return VG_OK;      // not handled: the caller falls back
+      flip = f;
+    }
+    p.flip = flip;
+    if ((size_t)p.N * p.H * p.W * p.Cs * Cfg::EB >= ((size_t)1 << 32)) return VG_OK;   // 32-bit piece offsets
+    p.dbg = g_dbg;
+    p.tilesX = (int)vg_ceil_div(p.OWl, Cfg::TW);
+    p.tilesY = (int)vg_ceil_div(p.OHl, Cfg::TH);
+    p.mtiles = p.N * p.tilesX * p.tilesY;
+    p.ntiles = p.Npad / Cfg::BN;
+    auto kern = igemm3_kernel<T, MI, NI, WM, WN, R, S>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    pack_taps(p);
+    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.nphases), dim3(Cfg::NT), Cfg::LDS, st, p);
+    VG_LAUNCH_CHECK();
+    *handled = true;
+  }
+  return VG_OK;
+}
+
+static int g_conv_kernel = 3;
+template <typename T, int R, int S> static int dispatch_igemm3_rs(const IgemmParams& p, hipStream_t st, bool* handled) {
+  if (p.Npad % 256 == 0) return launch_igemm3<T, 4, 2, 2, 4, R, S>(p, st, handled);   // 8x32 px x 256 ch
+  if (p.Npad == 128) return launch_igemm3<T, 4, 2, 4, 2, R, S>(p, st, handled);       // 16x32 px x 128 ch
+  if (p.Npad == 64) return launch_igemm3<T, 2, 2, 8, 1, R, S>(p, st, handled);        // 16x32 px x 64 ch
+  return VG_OK;
+}
+template <typename T> static int dispatch_igemm3(const IgemmParams& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if constexpr (sizeof(T) == 2) {
+    if (g_conv_kernel < 3 || p.ksplit > 1 || p.in_s != 1 || p.OWl < 24) return VG_OK;
+    if (p.ntaps == 9) return dispatch_igemm3_rs<T, 3, 3>(p, st, handled);
+    if (p.ntaps == 16) return dispatch_igemm3_rs<T, 4, 4>(p, st, handled);
+    if (p.ntaps == 4) return dispatch_igemm3_rs<T, 2, 2>(p, st, handled);
+  }
+  return VG_OK;
+}
+
+static bool g_use_igemm2 = true;
+extern "C" void vg_set_conv_kernel(int version) {
+  g_conv_kernel = version & 0xff;
+  g_use_igemm2 = g_conv_kernel != 1;
+  g_dbg = version >> 8;
+}
+
+template <typename T> static int dispatch_igemm2(const IgemmParams& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!g_use_igemm2 || p.ksplit > 1 || p.in_s != 1) return VG_OK;   // stride-2 gathers: the im2col-row kernel is faster
+  if (p.in_s == 1) {
+    if (p.Npad % 128 == 0) return launch_igemm2<T, 2, 2, 4, 2, 16>(p, st, handled);
+    if (p.Npad == 64) return launch_igemm2<T, 2, 2, 4, 1, 16>(p, st, handled);
+    if (p.Npad == 32) return launch_igemm2<T, 2, 1, 4, 1, 16>(p, st, handled);
+  } else {
+    if (p.Npad % 128 == 0) return launch_igemm2<T, 2, 2, 2, 2, 8>(p, st, handled);
+    if (p.Npad == 64) return launch_igemm2<T, 1, 2, 4, 1, 8>(p, st, handled);
+    if (p.Npad == 32) return launch_igemm2<T, 1, 1, 4, 1, 8>(p, st, handled);
+  }
+  return VG_OK;
+}
+
 template <typename T> static int dispatch_igemm(const IgemmParams& p, hipStream_t st) {
+  bool handled = false;
+  int rc3 = dispatch_igemm3<T>(p, st, &handled);
+  if (rc3 != VG_OK || handled) return rc3;
+  int rc2 = dispatch_igemm2<T>(p, st, &handled);
+  if (rc2 != VG_OK || handled) return rc2;
   if (p.Npad % 128 == 0) return launch_igemm<T, 2, 2, 2, 2>(p, st);   // 128 x 128
   if (p.Npad == 64) return launch_igemm<T, 2, 2, 4, 1>(p, st);        // 256 x 64
   if (p.Npad == 32) return launch_igemm<T, 2, 1, 4, 1>(p, st);        // 256 x 32
