@@ -59,10 +59,13 @@ def check_digests(g, grads, rtol=2e-4, k=4.0, name_map=lambda n: n):
     mathematically-zero gradient (fp noise on every implementation): for those
     only require 'tiny relative to the sibling weight gradient'."""
     n = 0
-    # module-level reproducibility floor: one parameter's recorded noise is a single sample (a LeakyReLU sign flip
-    # may or may not have hit it), so never go below the median noise of the module's parameters
-    ns = [float(v) for kk, v in g.items() if kk.startswith("noise:gd:") and float(v) < 1.0]
-    floor = float(np.median(ns)) if ns else 0.0
+    # Module-level reproducibility floor.  A LeakyReLU whose pre-activation is within rounding of 0 flips sign with
+    # the summation order; one flip moves every gradient upstream of it by 1e-3..1e-2 (rel-L2), on the reference
+    # itself (noise:dx, noise:gd:* = its own fp32 run vs float64) and between two of our own kernel generations
+    # (tests/gpu_hier_diff.py).  One parameter's recorded noise is a single sample of that event, so the floor of a
+    # module is the largest noise the reference showed anywhere in it (flip-free modules keep rtol).
+    ns = [float(v) for kk, v in g.items() if kk.startswith(("noise:gd:", "noise:dx")) and float(v) < 0.1]
+    floor = max(ns) if ns else 0.0
     for key, ref in g.items():
         if not key.startswith("gd:"):
             continue

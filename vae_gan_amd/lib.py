@@ -91,6 +91,8 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("VG_CONV_KERNEL"):      # ablation: 1 = im2col-row, 2 = + spatial-tile, 3 = + ping-pong (default)
+            lib.vg_set_conv_kernel(int(os.environ["VG_CONV_KERNEL"]))
         _lib = lib
     return _lib
 
