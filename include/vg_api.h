@@ -43,9 +43,12 @@ typedef struct {
   int dtype;          /* VG_F32 | VG_BF16                                        */
 } vg_conv_desc;
 
-/* Development/ablation switch: 1 = im2col-row implicit GEMM only, anything else = spatial-tile (halo) kernel
- * where it applies (default). */
+/* Development/ablation switch: 1 = im2col-row implicit GEMM only, 2 = + spatial-tile (halo) kernel where it
+ * applies, 3 = + ping-pong spatial-tile kernel where it applies (default). */
 void vg_set_conv_kernel(int version);
+/* Name of the gather-GEMM kernel variant the calling thread's last vg_conv_fwd / vg_conv_dgrad launched
+ * (e.g. "igemm3<bf16,4,2,2,4,3x3>"); bench.py keys its live per-kernel timings on it. */
+const char* vg_last_conv_kernel(void);
 
 /* ---- weight packing ---------------------------------------------------------------------- */
 /* Bytes of the packed forward (transposed=0) or dgrad (transposed=1) weight image. */

@@ -93,6 +93,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // ring depth: as many 64-byte-chunk stages as fit next to a second resident block (<= 80 KiB per block)
 __host__ __device__ constexpr int igemm_stages(int bm, int bn) { return (bm + bn) * 64 * 4 <= 65536 ? 4 : 3; }
 
+static thread_local char g_last_kernel[64] = "";
+extern "C" const char* vg_last_conv_kernel(void) { return g_last_kernel; }
+template <typename T> static const char* tname() { return sizeof(T) == 2 ? "bf16" : "f32"; }
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int MI, int NI, int WM, int WN>
@@ -327,6 +331,7 @@ static int launch_igemm(const IgemmParams& p0, hipStream_t st) {
   }
   dim3 grid(p.mtiles * p.ntiles, p.nphases, p.ksplit);
   pack_taps(p);
+  snprintf(g_last_kernel, sizeof g_last_kernel, "igemm<%s,%d,%d,%d,%d>%s", tname<T>(), MI, NI, WM, WN, p.ksplit > 1 ? "+splitk" : "");
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -608,6 +613,7 @@ static int launch_igemm2(const IgemmParams& p0, hipStream_t st, bool* handled) {
     attr_set = true;
   }
   pack_taps(p);
+  snprintf(g_last_kernel, sizeof g_last_kernel, "igemm2<%s,%d,%d,%d,%d,%d>", tname<T>(), MI, NI, WM, WN, TH);
   hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.nphases), dim3(NT), lds, st, p);
   VG_LAUNCH_CHECK();
   *handled = true;
@@ -947,6 +953,7 @@ static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
       attr_set = true;
     }
     pack_taps(p);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm3<%s,%d,%d,%d,%d,%dx%d>", tname<T>(), MI, NI, WM, WN, R, S);
     hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.nphases), dim3(Cfg::NT), Cfg::LDS, st, p);
     VG_LAUNCH_CHECK();
     *handled = true;

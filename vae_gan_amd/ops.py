@@ -42,6 +42,8 @@ class KernelProfile:
         e0.record()
         rc = fn()
         e1.record()
+        if name is None:      # gather-GEMM launch: ask the library which kernel variant it dispatched
+            name = L.load().vg_last_conv_kernel().decode()
         self.records.append((name, flops, e0, e1))
         return rc
 
@@ -57,12 +59,6 @@ class KernelProfile:
 
 
 PROFILE = [None]   # set PROFILE[0] = KernelProfile() to time conv launches
-
-
-def _tile_name(npad: int, dt) -> str:
-    t = "bf16" if dt == torch.bfloat16 else "f32"
-    v = "2,2,2,2" if npad % 128 == 0 else ("2,2,4,1" if npad == 64 else "2,1,4,1")
-    return f"igemm_kernel<{t},{v}>"
 
 
 def _conv_flops(d) -> float:
@@ -214,7 +210,7 @@ class Conv2dFn(torch.autograd.Function):
         y = torch.empty(n, d.oh, d.ow, ycs, dtype=dt, device=x.device)
         stats = _stats_buf(_npad(co), x.device) if want_stats else None
         lib = L.load()
-        L.check(_timed(_tile_name(_npad(co), dt), _conv_flops(d),
+        L.check(_timed(None, _conv_flops(d),
                        lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(),
                                                L.ptr(stats), act, 0, L.stream())), "conv_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
@@ -235,7 +231,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpt = ctx.packs.get(weight, d, 1, x.dtype)
             dx = torch.empty_like(x)
-            L.check(_timed(_tile_name(_npad(d.ci), x.dtype), _conv_flops(d),
+            L.check(_timed(None, _conv_flops(d),
                            lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
                                                      L.ACT_NONE, 0, L.stream())), "conv_dgrad")
         if ctx.needs_input_grad[1]:
@@ -264,7 +260,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         y = torch.empty(n, oh, ow, ycs, dtype=dt, device=x.device)
         stats = _stats_buf(_npad(cout_t), x.device) if want_stats else None
         lib = L.load()
-        L.check(_timed(_tile_name(_npad(cout_t), dt), _conv_flops(d),
+        L.check(_timed(None, _conv_flops(d),
                        lambda: lib.vg_conv_dgrad(C.byref(d), x.data_ptr(), wpt.data_ptr(), L.ptr(bias), y.data_ptr(),
                                                  L.ptr(stats), act, 0, L.stream())), "convT_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
@@ -285,7 +281,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wp = ctx.packs.get(weight, d, 0, x.dtype)
             dx = torch.empty_like(x)
-            L.check(_timed(_tile_name(_npad(d.co), x.dtype), _conv_flops(d),
+            L.check(_timed(None, _conv_flops(d),
                            lambda: lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None,
                                                    L.ACT_NONE, 0, L.stream())), "convT_dgrad")
         if ctx.needs_input_grad[1]:
