@@ -46,6 +46,8 @@ typedef struct {
 /* Development/ablation switch: 1 = im2col-row implicit GEMM only, 2 = + spatial-tile (halo) kernel where it
  * applies, 3 = + ping-pong spatial-tile kernel where it applies (default). */
 void vg_set_conv_kernel(int version);
+/* Same for the weight gradient: 1 = per-tap pixel-reduction kernel only, 3 = + spatial-tile kernel (default). */
+void vg_set_wgrad_kernel(int version);
 /* Name of the gather-GEMM kernel variant the calling thread's last vg_conv_fwd / vg_conv_dgrad launched
  * (e.g. "igemm3<bf16,4,2,2,4,3x3>"); bench.py keys its live per-kernel timings on it. */
 const char* vg_last_conv_kernel(void);

@@ -23,6 +23,15 @@ def run(lib, d, x, wp, wpt, gy, mode, dtype):
     torch.cuda.synchronize()
     return y.float(), dx.float(), y2.float(), dx2.float(), stats.sum(0).float()
 
+
+def run_wgrad(lib, d, x, gy, mode):
+    lib.vg_set_wgrad_kernel(mode)
+    ws = torch.empty(lib.vg_conv_wgrad_ws_bytes(C.byref(d)) // 4, dtype=torch.float32, device="cuda")
+    dw = torch.full((d.co, d.ci, d.r, d.s), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), L.stream()), "wgrad")
+    torch.cuda.synchronize()
+    return dw
+
 def main(exit=True):
     lib = L.load(); bad = 0
     shapes = []
@@ -49,7 +58,11 @@ def main(exit=True):
                     e = rel(a, b)
                     if not e <= tol:
                         print(f"MISMATCH v{mode} {nm} {shp} {str(dtype)[6:]} rel={e:.3e}", flush=True); bad += 1
+            e = rel(run_wgrad(lib, d, x, gy, 3), run_wgrad(lib, d, x, gy, 1))
+            if not e <= 2e-5:
+                print(f"MISMATCH wgrad {shp} {str(dtype)[6:]} rel={e:.3e}", flush=True); bad += 1
     lib.vg_set_conv_kernel(3)
+    lib.vg_set_wgrad_kernel(3)
     print("mismatches:", bad)
     if exit:
         sys.exit(1 if bad else 0)

@@ -1399,6 +1399,219 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t st) {
   return VG_OK;
 }
 
+// =============================================================================================
+// wgrad3: spatial-tile weight gradient for 3x3 stride-1 convolutions (bf16).
+//
+// The kernel above gives every tap its own blocks, so x and dy travel L2 -> LDS once per tap (18 tensor
+// passes for a 3x3) and it is bound by that traffic.  Here a block of 8 waves owns one (BO x BC) slab of
+// dW for ALL nine taps and walks over 4 x 32 pixel tiles of the output: per tile the dy tile and the x halo
+// (6 x 34 pixels) are brought in ONCE by LDS-DMA, three tiles deep, and the taps read their shifted
+// [pixel][channel] operands with transposed LDS reads (plain 64-byte pixel rows are conflict free for
+// ds_read_b64_tr_b16, so a tap shift is an immediate offset).  A wave keeps one 32 x 32 block of every tap
+// in registers (144 accumulators) over its share of the tile rows; the slab is added to the f32
+// workspace with atomics once, at the end.  One barrier per tile, counted vmcnt.
+// =============================================================================================
+template <int NOB, int NCB, int KS>
+struct Wg3Cfg {
+  static constexpr int TH = 4, TW = 32, R = 3, S = 3, NTAPS = 9;
+  static constexpr int HH = TH + R - 1, HS = TW + S - 1;              // 6 x 34 halo pixels
+  static constexpr int DYP = TH * TW / 16;                            // 16-pixel (1 KiB) DMA pieces per dy chunk image
+  static constexpr int XP = (HH * HS + 15) / 16;                      // ... per x halo chunk image
+  static constexpr int DYB = DYP * 1024, XB = XP * 1024;
+  static constexpr int STAGE = NOB * DYB + NCB * XB;
+  static constexpr int NPIECE = NOB * DYP + NCB * XP;
+  static constexpr int PR = (NPIECE + 7) / 8;                         // DMA pieces per wave per tile
+  static constexpr int NST = 3;
+  static constexpr int LDS = NST * STAGE;
+  static constexpr int BO = 32 * NOB, BC = 32 * NCB;
+};
+
+template <int NOB, int NCB, int KS>
+__global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
+  typedef Wg3Cfg<NOB, NCB, KS> Cfg;
+  static_assert(NOB * NCB * KS == 8, "8 waves");
+  constexpr int TH = Cfg::TH, TW = Cfg::TW, HS = Cfg::HS, HH = Cfg::HH, NTAPS = Cfg::NTAPS, PR = Cfg::PR;
+  constexpr int DYP = Cfg::DYP, XP = Cfg::XP, DYB = Cfg::DYB, XB = Cfg::XB, STAGE = Cfg::STAGE, NST = Cfg::NST;
+  constexpr int ROWS = TH / KS, KSTEPS = ROWS * 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) bf16x4* tr_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = wave % KS, cb = (wave / KS) % NCB, ob = wave / (KS * NCB);
+  const int h = lane >> 5, l32 = lane & 31;
+  const int pairs = p.otiles * p.ctiles;
+  const int pair = blockIdx.x % pairs, g = blockIdx.x / pairs, G = gridDim.x / pairs;
+  const int o0 = (pair / p.ctiles) * Cfg::BO, c0 = (pair % p.ctiles) * Cfg::BC;
+  const int tilesX = (p.OW + TW - 1) / TW, tilesY = (p.OH + TH - 1) / TH;
+  const int tpi = tilesX * tilesY, ntiles = p.N * tpi;
+  const int pad = -p.dy_[0];
+  const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
+  const unsigned char* __restrict__ dyg = (const unsigned char*)p.dy;
+  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
+
+  // ---- DMA pieces of this wave: round r moves piece u = r*8 + wave (wrapped: the spare slots of the last
+  // round repeat early pieces, same bytes to the same place, so every wave issues exactly PR per tile)
+  unsigned poff[PR];        // byte offset from the tile's origin pixel (dy: (ty0,tx0); x: (ty0-pad, tx0-pad))
+  int pyx[PR];              // local (y << 16 | x) of the lane's pixel; y = 0x4000 marks a lane that always reads zeros
+  int pdst[PR];             // LDS offset inside a stage (wave-uniform)
+  bool pisdy[PR];
+#pragma unroll
+  for (int r = 0; r < PR; ++r) {
+    int u = r * 8 + wave;
+    if (u >= Cfg::NPIECE) u -= Cfg::NPIECE;
+    const bool isdy = u < NOB * DYP;
+    const int v = isdy ? u : u - NOB * DYP;
+    const int chunk = isdy ? v / DYP : v / XP, grp = isdy ? v % DYP : v % XP;
+    const int lpx = grp * 16 + (lane >> 2), slot = lane & 3;
+    pisdy[r] = isdy;
+    pdst[r] = isdy ? chunk * DYB + grp * 1024 : NOB * DYB + chunk * XB + grp * 1024;
+    if (isdy) {
+      const int y = lpx / TW, x = lpx % TW;
+      const bool ok = o0 + chunk * 32 < p.Os;
+      poff[r] = (unsigned)((((y * p.OW + x) * p.Os) + o0 + chunk * 32) * 2 + slot * 16);
+      pyx[r] = ((ok ? y : 0x4000) << 16) | x;
+    } else {
+      const int y = lpx / HS, x = lpx % HS;
+      const bool ok = c0 + chunk * 32 < p.Cs && lpx < HH * HS;
+      poff[r] = (unsigned)((((y * p.W + x) * p.Cs) + c0 + chunk * 32) * 2 + slot * 16);
+      pyx[r] = ((ok ? y : 0x4000) << 16) | x;
+    }
+  }
+  auto tile_pos = [&](int t, int& img, int& ty0, int& tx0) {
+    img = t / tpi;
+    const int rem = t - img * tpi;
+    const int ty = rem / tilesX;
+    ty0 = ty * TH; tx0 = (rem - ty * tilesX) * TW;
+  };
+  auto issue_piece = [&](int r, int img, int ty0, int tx0, int stage) {
+    const int ly = pyx[r] >> 16, lx = pyx[r] & 0xffff;
+    const unsigned char* src;
+    if (pisdy[r]) {
+      const bool ok = ty0 + ly < p.OH && tx0 + lx < p.OW;
+      const unsigned char* base = dyg + ((size_t)((size_t)img * p.OH + ty0) * p.OW + tx0) * p.Os * 2;
+      src = ok ? base + poff[r] : zsrc;
+    } else {
+      const int iy = ty0 - pad + ly, ix = tx0 - pad + lx;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned char* base = xg + ((long)((long)img * p.H + ty0 - pad) * p.W + tx0 - pad) * p.Cs * 2;
+      src = ok ? base + poff[r] : zsrc;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(smem + stage * STAGE + pdst[r]), 16, 0, 0);
+  };
+
+  f32x16 acc[NTAPS];
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposed-read lane term: lane (tq = li>>2, tp = li&3) of a 16-lane group addresses pixel row tq, channels 4tp..4tp+3
+  const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+  const int lterm = (8 * h + tq) * 64 + (16 * g16 + 4 * tp) * 2;
+  const int abase = ob * DYB + ks * TW * 64 + lterm;                 // dy image of this wave's o block, first own row
+  const int bbase = NOB * DYB + cb * XB + ks * HS * 64 + lterm;      // x halo image of this wave's c block
+
+  int t = g;
+  {
+    int img, ty0, tx0;
+#pragma unroll
+    for (int pre = 0; pre < 2; ++pre) {
+      if (g + pre * G < ntiles) {
+        tile_pos(g + pre * G, img, ty0, tx0);
+#pragma unroll
+        for (int r = 0; r < PR; ++r) issue_piece(r, img, ty0, tx0, pre);
+      }
+    }
+  }
+  int stage = 0;
+  for (; t < ntiles; t += G) {
+    if (t + G < ntiles) wait_vmcnt<PR>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool more = t + 2 * G < ntiles;
+    int nimg = 0, nty0 = 0, ntx0 = 0;
+    if (more) tile_pos(t + 2 * G, nimg, nty0, ntx0);
+    const int nstage = stage + 2 >= NST ? stage + 2 - NST : stage + 2;
+    const unsigned char* sA = smem + stage * STAGE + abase;
+    const unsigned char* sB = smem + stage * STAGE + bbase;
+#pragma unroll
+    for (int kstep = 0; kstep < KSTEPS; ++kstep) {
+      const int j = kstep >> 1, kx = kstep & 1;
+      const int y = j * KS;                                           // + ks (in the base)
+      bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW + kx * 16) * 64));
+      bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW + kx * 16 + 4) * 64));
+      const bf16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+      for (int tap = 0; tap < NTAPS; ++tap) {
+        const int hp = (y + tap / 3) * HS + kx * 16 + tap % 3;
+        bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + hp * 64));
+        bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64));
+        const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+      }
+      // prefetch of tile t+2G, spread over the k steps
+      if (more) {
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+          if (r * KSTEPS / PR == kstep) issue_piece(r, nimg, nty0, ntx0, nstage);
+      }
+    }
+    stage = stage + 1 == NST ? 0 : stage + 1;
+  }
+
+  // acc[tap][r]: row (o) = (r&3) + 8*(r>>2) + 4*h, column (c) = l32
+  const size_t rowstride = (size_t)NTAPS * p.Cpad;
+  const int c = c0 + cb * 32 + l32;
+  if (c < p.Cpad) {
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (o < p.Opad) unsafeAtomicAdd(&p.dw[(size_t)o * rowstride + (size_t)tap * p.Cpad + c], acc[tap][r]);
+      }
+  }
+}
+
+template <int NOB, int NCB, int KS>
+static int launch_wgrad3(const WgradParams& p0, hipStream_t st) {
+  typedef Wg3Cfg<NOB, NCB, KS> Cfg;
+  WgradParams p = p0;
+  p.otiles = (int)vg_ceil_div(p.Opad, Cfg::BO);
+  p.ctiles = (int)vg_ceil_div(p.Cpad, Cfg::BC);
+  const int pairs = p.otiles * p.ctiles;
+  const int ntiles = p.N * (int)vg_ceil_div(p.OH, Cfg::TH) * (int)vg_ceil_div(p.OW, Cfg::TW);
+  int G = (int)vg_ceil_div(256, pairs);                      // one block per CU (LDS-limited), at least
+  if (G > ntiles) G = ntiles;
+  auto kern = wgrad3_kernel<NOB, NCB, KS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pairs * G), dim3(512), Cfg::LDS, st, p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+static int g_wgrad_kernel = 3;
+extern "C" void vg_set_wgrad_kernel(int version) { g_wgrad_kernel = version; }
+
+// returns true when the spatial-tile kernel took the launch
+static bool dispatch_wgrad3(const WgradParams& p, int R, int S, int dtype, hipStream_t st, int* rc) {
+  if (g_wgrad_kernel < 3 || dtype != VG_BF16 || p.in_s != 1 || R != 3 || S != 3 || p.OW < 24) return false;
+  if ((size_t)p.N * p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31) * 2 || (size_t)p.N * p.OH * p.OW * p.Os * 2 >= ((size_t)1 << 32))
+    return false;                                            // 32-bit piece offsets inside one image are all we need, keep it simple
+  if (p.Opad <= 32) *rc = launch_wgrad3<1, 2, 4>(p, st);
+  else if (p.Cpad <= 32) *rc = launch_wgrad3<2, 1, 4>(p, st);
+  else *rc = launch_wgrad3<2, 2, 2>(p, st);
+  return true;
+}
+
 template <typename T> static int dispatch_wgrad(const WgradParams& p, hipStream_t st) {
   const bool o128 = p.Opad >= 128, c128 = p.Cpad >= 128;
   const bool o32 = p.Opad <= 32, c32 = p.Cpad <= 32;
@@ -1448,7 +1661,8 @@ extern "C" int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* d
   for (int r = 0; r < d->r; ++r)
     for (int s = 0; s < d->s; ++s) { p.dy_[r * d->s + s] = (signed char)(r - d->pad); p.dx_[r * d->s + s] = (signed char)(s - d->pad); }
   VG_HIP(hipMemsetAsync(ws, 0, vg_conv_wgrad_ws_bytes(d), st));
-  rc = d->dtype == VG_BF16 ? dispatch_wgrad<bf16_t>(p, st) : dispatch_wgrad<float>(p, st);
+  if (!dispatch_wgrad3(p, d->r, d->s, d->dtype, st, &rc))
+    rc = d->dtype == VG_BF16 ? dispatch_wgrad<bf16_t>(p, st) : dispatch_wgrad<float>(p, st);
   if (rc) return rc;
   const long total = (long)d->co * d->ci * d->r * d->s;
   int blocks = (int)((total + 255) / 256);

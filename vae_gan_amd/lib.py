@@ -38,6 +38,7 @@ SIGNATURES = {
     "vg_last_error": (C.c_char_p, []),
     "vg_version": (_I, []),
     "vg_set_conv_kernel": (None, [_I]),
+    "vg_set_wgrad_kernel": (None, [_I]),
     "vg_last_conv_kernel": (C.c_char_p, []),
     "vg_conv_packed_bytes": (C.c_size_t, [_DP, _I]),
     "vg_conv_pack_weight": (_I, [_DP, _I, _P, _P, _P]),
