@@ -111,16 +111,21 @@ int vg_channel_stats(const void* x, double* stats, int64_t rows, int cs, int c, 
 int vg_bn_act_fwd(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
                   int cs, int c, int act, int dtype, void* stream);
 /* Backward, pass 1: sums[rep][2][cpad] (f64, zeroed) += {sum dz, sum dz*xhat} with
- * dz = dout * (y > 0 ? 1 : 0.2) (act=LRELU) and xhat = (x-mean)*invstd. */
+ * dz = dout * (y > 0 ? 1 : 0.2) (act=LRELU) and xhat = (x-mean)*invstd.
+ * y may be NULL when the forward had no residual and act is LRELU or NONE: the mask is then recomputed as
+ * x*scale+shift > 0 with the forward's own scale/shift (vg_bn_finalize), which saves reading y. */
 int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
-                     double* sums, int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream);
+                     const float* scale, const float* shift, double* sums, int64_t rows, int cs, int c, int cpad,
+                     int act, int dtype, void* stream);
 /* Backward, pass 2: dx = gamma*invstd*(dz - sum_dz/n - xhat*sum_dzxhat/n); dres = dz (optional);
  * dgamma = sum_dzxhat, dbeta = sum_dz (f32 [c]). */
 /* NOTE: `sums` must be followed by 3*cpad f32 of scratch (coefficients), i.e. allocate
  * VG_STATS_REPLICAS*2*cpad f64 + 3*cpad f32. */
+/* y may be NULL under the same conditions as in vg_bn_bwd_reduce. */
 int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
-                    const float* gamma, const double* sums, void* dx, void* dres, float* dgamma, float* dbeta,
-                    int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream);
+                    const float* scale, const float* shift, const float* gamma, const double* sums, void* dx,
+                    void* dres, float* dgamma, float* dbeta, int64_t rows, int cs, int c, int cpad, int act,
+                    int dtype, void* stream);
 /* Plain elementwise activation backward (no BN): dx = dout * act'(y). */
 int vg_act_bwd(const void* dout, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
 /* a += b (elementwise, `dtype`): gradient fan-in of the residual skip. */

@@ -121,23 +121,28 @@ extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const floa
 // accumulators in registers over its rows, then the block combines through LDS and issues one f64
 // atomic per channel.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// XMASK: the LeakyReLU mask is recomputed from x with the forward pass's own scale/shift (same expression, same
+// rounding) instead of being read back from y: one tensor pass less.
+template <typename T, bool XMASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, double* __restrict__ sums,
+                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, double* __restrict__ sums,
                                                             int64_t rows, int cs, int c, int cpad, int act) {
   constexpr int PIECE = Elt<T>::PIECE;
   __shared__ float red[256 * PIECE * 2];
   const int ppr = cs / PIECE;                        // pieces per row (<= 256 guaranteed by launcher)
   const int rpb = 256 / ppr;                         // rows handled per block pass
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
-  float a1[PIECE], a2[PIECE], mu[PIECE], is[PIECE];
+  float a1[PIECE], a2[PIECE], mu[PIECE], is[PIECE], sc[PIECE], sh[PIECE];
 #pragma unroll
   for (int e = 0; e < PIECE; ++e) {
     a1[e] = 0.f; a2[e] = 0.f;
     const int ch = pc * PIECE + e;
     mu[e] = ch < c ? mean[ch] : 0.f;
     is[e] = ch < c ? invstd[ch] : 0.f;
+    sc[e] = (XMASK && ch < c) ? scale[ch] : 0.f;
+    sh[e] = (XMASK && ch < c) ? shift[ch] : 0.f;
   }
   double d1[PIECE], d2[PIECE];
 #pragma unroll
@@ -148,12 +153,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       const size_t off = (size_t)r * cs + pc * PIECE;
       Piece<T> g, o, v;
       g.v = *(const decltype(g.v)*)(dout + off);
-      o.v = *(const decltype(o.v)*)(y + off);
+      if (!XMASK) o.v = *(const decltype(o.v)*)(y + off);
       v.v = *(const decltype(v.v)*)(x + off);
 #pragma unroll
       for (int e = 0; e < PIECE; ++e) {
         float dz = g.get(e);
-        if (act == VG_ACT_LRELU && !(o.get(e) > 0.f)) dz *= VG_LRELU_SLOPE;
+        const float yv = XMASK ? v.get(e) * sc[e] + sh[e] : o.get(e);
+        if (act == VG_ACT_LRELU && !(yv > 0.f)) dz *= VG_LRELU_SLOPE;
         const float xh = (v.get(e) - mu[e]) * is[e];
         a1[e] += dz;
         a2[e] += dz * xh;
@@ -185,16 +191,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
-                                double* sums, int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream) {
-  VG_REQUIRE(dout && y && x && mean && invstd && sums && rows > 0 && cs >= c && cpad >= c, "bn_bwd_reduce: bad arguments");
+                                const float* scale, const float* shift, double* sums, int64_t rows, int cs, int c, int cpad,
+                                int act, int dtype, void* stream) {
+  VG_REQUIRE(dout && x && mean && invstd && sums && rows > 0 && cs >= c && cpad >= c, "bn_bwd_reduce: bad arguments");
+  VG_REQUIRE(y || (scale && shift), "bn_bwd_reduce: need y, or scale and shift to recompute the activation mask from x");
+  const bool xmask = y == nullptr && act == VG_ACT_LRELU;
+  VG_REQUIRE(y || act == VG_ACT_LRELU || act == VG_ACT_NONE, "bn_bwd_reduce: y is required for this activation");
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "bn_bwd_reduce: channel stride %d unsupported", cs);
   const int rpb = 256 / (cs / piece);
   int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 16);
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, sums, rows, cs, c, cpad, act);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, sums, rows, cs, c, cpad, act);
+  if (y == nullptr && !xmask) y = x;    // no activation: the value is never looked at
+  dim3 g((unsigned)blocks), b(256);
+  if (dtype == VG_BF16) {
+    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
+  } else {
+    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
+  }
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -220,10 +237,11 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
   if (dbeta) dbeta[ch] = (float)s1;
 }
 
-template <typename T, bool HAS_DRES>
+template <typename T, bool HAS_DRES, bool XMASK>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const T* __restrict__ x, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ coef,
                                                            T* __restrict__ dx, T* __restrict__ dres, int64_t rows,
                                                            int ppr, int c, int cpad, int act) {
   constexpr int PIECE = Elt<T>::PIECE;
@@ -231,15 +249,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
   if (rr >= rpb) return;
   // d = a*(dz - m1 - xh*m2), xh = (x-mu)*is  ==  a*dz - (a*m1 - a*m2*is*mu) - (a*m2*is)*x
-  float ca[PIECE], cb[PIECE], cx[PIECE];
+  float ca[PIECE], cb[PIECE], cx[PIECE], sc[PIECE], sh[PIECE];
 #pragma unroll
   for (int e = 0; e < PIECE; ++e) {
     const int ch = pc * PIECE + e;
     if (ch < c) {
       const float a = coef[ch], m1 = coef[cpad + ch], m2 = coef[2 * cpad + ch], mu = mean[ch], is = invstd[ch];
       ca[e] = a; cx[e] = a * m2 * is; cb[e] = a * m1 - cx[e] * mu;
+      sc[e] = XMASK ? scale[ch] : 0.f; sh[e] = XMASK ? shift[ch] : 0.f;
     } else {
-      ca[e] = 0.f; cx[e] = 0.f; cb[e] = 0.f;
+      ca[e] = 0.f; cx[e] = 0.f; cb[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f;
     }
   }
   const size_t cs = (size_t)ppr * PIECE;
@@ -247,12 +266,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const size_t off = (size_t)r * cs + pc * PIECE;
     Piece<T> g, o, v, rx, rd;
     g.v = *(const decltype(g.v)*)(dout + off);
-    o.v = *(const decltype(o.v)*)(y + off);
+    if (!XMASK) o.v = *(const decltype(o.v)*)(y + off);
     v.v = *(const decltype(v.v)*)(x + off);
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) {
       float dz = g.get(e);
-      if (act == VG_ACT_LRELU && !(o.get(e) > 0.f)) dz *= VG_LRELU_SLOPE;
+      const float yv = XMASK ? v.get(e) * sc[e] + sh[e] : o.get(e);
+      if (act == VG_ACT_LRELU && !(yv > 0.f)) dz *= VG_LRELU_SLOPE;
       if (pc * PIECE + e >= c) dz = 0.f;
       rx.set(e, ca[e] * dz - cb[e] - cx[e] * v.get(e));
       if (HAS_DRES) rd.set(e, dz);
@@ -263,9 +283,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
-                               const float* gamma, const double* sums, void* dx, void* dres, float* dgamma, float* dbeta,
-                               int64_t rows, int cs, int c, int cpad, int act, int dtype, void* stream) {
-  VG_REQUIRE(dout && y && x && mean && invstd && sums && dx && rows > 0 && cs >= c && cpad >= c, "bn_bwd_apply: bad arguments");
+                               const float* scale, const float* shift, const float* gamma, const double* sums, void* dx,
+                               void* dres, float* dgamma, float* dbeta, int64_t rows, int cs, int c, int cpad, int act,
+                               int dtype, void* stream) {
+  VG_REQUIRE(dout && x && mean && invstd && sums && dx && rows > 0 && cs >= c && cpad >= c, "bn_bwd_apply: bad arguments");
+  VG_REQUIRE(y || (scale && shift), "bn_bwd_apply: need y, or scale and shift to recompute the activation mask from x");
+  VG_REQUIRE(y || act == VG_ACT_LRELU || act == VG_ACT_NONE, "bn_bwd_apply: y is required for this activation");
+  const bool xmask = y == nullptr && act == VG_ACT_LRELU;
+  if (y == nullptr && !xmask) y = x;
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "bn_bwd_apply: channel stride %d unsupported", cs);
   hipStream_t st = (hipStream_t)stream;
@@ -276,13 +301,17 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   const int ppr = cs / piece;
   const int64_t np = rows;
   dim3 g(row_blocks(rows, 256 / ppr, 8)), b(256);
+#define VG_BN_APPLY(T, DR, XM)                                                                                      \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DR, XM>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
+                     scale, shift, coef, (T*)dx, (T*)dres, np, ppr, c, cpad, act)
   if (dtype == VG_BF16) {
-    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, coef, (bf16_t*)dx, (bf16_t*)dres, np, ppr, c, cpad, act);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, coef, (bf16_t*)dx, (bf16_t*)nullptr, np, ppr, c, cpad, act);
+    if (dres) { if (xmask) VG_BN_APPLY(bf16_t, true, true); else VG_BN_APPLY(bf16_t, true, false); }
+    else { if (xmask) VG_BN_APPLY(bf16_t, false, true); else VG_BN_APPLY(bf16_t, false, false); }
   } else {
-    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, coef, (float*)dx, (float*)dres, np, ppr, c, cpad, act);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, coef, (float*)dx, (float*)nullptr, np, ppr, c, cpad, act);
+    if (dres) { if (xmask) VG_BN_APPLY(float, true, true); else VG_BN_APPLY(float, true, false); }
+    else { if (xmask) VG_BN_APPLY(float, false, true); else VG_BN_APPLY(float, false, false); }
   }
+#undef VG_BN_APPLY
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
