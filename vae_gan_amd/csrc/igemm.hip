@@ -10,6 +10,7 @@
 // LDS tiles are [row][64 B] with the 16-byte slot XOR-swizzled by (row>>2)&3, which makes both
 // the ds_write_b128 staging stores and the ds_read_b128 fragment loads bank-conflict free.
 #include "common.h"
+#include <type_traits>
 
 #ifdef VG_ABLATE   // timing ablations only (results are wrong): see tests/gpu_conv_ablate.py
 #define VG_DBG(bit) (p.dbg & (bit))
@@ -841,34 +842,73 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
   wait_vmcnt<0>();   // weight tiles prefetched past the end
   __syncthreads();   // every fragment read is done before the staging area aliases the rings
 
-  // ---- epilogue: bias, BN statistics, activation; each wave stages one 32-row block at a time in T
+  // ---- epilogue: bias, BN statistics, activation; each wave stages one 32-row block (= one tile row) at a time in T.
+  // The common case (tile and channel block fully inside, no sigmoid) runs a lean packed-f32 path: with
+  // 64..128 accumulators per lane the epilogue is thousands of VALU cycles per block otherwise.
   T* wt = (T*)(smem + wave * WTILE);            // [32][32*NI]
   constexpr int WN_COLS = 32 * NI;
   constexpr int PPR = WN_COLS / PIECE;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   T* __restrict__ yg = (T*)p.y;
-  float bv[NI], a1[NI], a2[NI];
+  float bv[NI];
+  f32x2 a1[NI], a2[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int n = n0 + (wn * NI + j) * 32 + l32;
     bv[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
-    a1[j] = a2[j] = 0.f;
+    a1[j] = f32x2{0.f, 0.f}; a2[j] = f32x2{0.f, 0.f};
   }
+  const bool fast = sizeof(T) == 2 && ty0 + TH <= p.OHl && tx0 + TW <= p.OWl && n0 + BN <= p.Nout && p.act != VG_ACT_SIGMOID;
+  const bool want_stats = p.stats != nullptr;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const unsigned* rp = rowpix + (wm * MI + i) * 32;
+    if (fast) {
+      T* wl = wt + 4 * h * WN_COLS + l32;          // lane base; everything else below is an immediate
+      auto lean = [&](auto LR, auto ST) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + (wn * NI + j) * 32 + l32;
+        for (int j = 0; j < NI; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = acc[i][j][r] + bv[j];
-        v = Elt<T>::to_f(Elt<T>::from_f(v));
-        if (rp[lrow] != 0xFFFFFFFFu) { a1[j] += v; a2[j] += v * v; }
-        if (p.act == VG_ACT_LRELU) v = vg_lrelu(v);
-        else if (p.act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
-        if (n >= p.Nout) v = 0.f;
-        wt[lrow * WN_COLS + j * 32 + l32] = Elt<T>::from_f(v);
+          for (int r2 = 0; r2 < 8; ++r2) {
+            const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2);                // rows row, row + 1 (+ 4h in wl)
+            f32x2 v = f32x2{acc[i][j][r], acc[i][j][r + 1]} + bv[j];
+            bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+            v = __builtin_convertvector(q, f32x2);
+            if (decltype(ST)::value) { a1[j] += v; a2[j] += v * v; }
+            if (decltype(LR)::value) {
+              const f32x2 w = v * VG_LRELU_SLOPE;
+              f32x2 m;
+              asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
+              asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
+              q = __builtin_convertvector(m, bf16x2_t);
+            }
+            wl[row * WN_COLS + j * 32] = q[0];
+            wl[(row + 1) * WN_COLS + j * 32] = q[1];
+          }
+        }
+      };
+      if constexpr (sizeof(T) == 2) {
+        typedef std::integral_constant<bool, true> Yes;
+        typedef std::integral_constant<bool, false> No;
+        if (p.act == VG_ACT_LRELU) { if (want_stats) lean(Yes{}, Yes{}); else lean(Yes{}, No{}); }
+        else { if (want_stats) lean(No{}, Yes{}); else lean(No{}, No{}); }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + (wn * NI + j) * 32 + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float v = acc[i][j][r] + bv[j];
+          v = Elt<T>::to_f(Elt<T>::from_f(v));
+          if (rp[lrow] != 0xFFFFFFFFu) { a1[j][0] += v; a2[j][0] += v * v; }
+          if (p.act == VG_ACT_LRELU) v = vg_lrelu(v);
+          else if (p.act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
+          if (n >= p.Nout) v = 0.f;
+          wt[lrow * WN_COLS + j * 32 + l32] = Elt<T>::from_f(v);
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -892,10 +932,11 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  if (p.stats != nullptr) {
+  if (want_stats) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const float s1 = a1[j] + __shfl_xor(a1[j], 32, 64), s2 = a2[j] + __shfl_xor(a2[j], 32, 64);
+      const float t1 = a1[j][0] + a1[j][1], t2 = a2[j][0] + a2[j][1];
+      const float s1 = t1 + __shfl_xor(t1, 32, 64), s2 = t2 + __shfl_xor(t2, 32, 64);
       if (h == 0) {
         const int col = (wn * NI + j) * 32 + l32;
         red[(wm * BN + col) * 2 + 0] = s1;
