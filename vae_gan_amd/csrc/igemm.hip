@@ -1639,14 +1639,214 @@ static int launch_wgrad3(const WgradParams& p0, hipStream_t st) {
   return VG_OK;
 }
 
+// =============================================================================================
+// wgrad3s2: the same for 4x4 stride-2 pad-1 convolutions (bf16).  x[2oy+r-1][2ox+s-1] is a stride-1 gather on
+// the four parity planes X_ab[i][j] = x[2i-a][2j-b] (a = (r+1)&1, row offset r>>1; likewise b, s), so the
+// halo of a 4 x 16 output tile is kept in LDS as four 5 x 17 pixel planes and every tap again reads consecutive
+// pixel rows (conflict-free transposed reads at immediate offsets).  A wave keeps one 32 x 32 block for the 8
+// taps of one row parity (128 accumulators); waves = NOB x NCB x 2 tap halves x KS row splits.
+// =============================================================================================
+template <int NOB, int NCB, int KS>
+struct Wg3s2Cfg {
+  static constexpr int TH = 4, TW = 16, PH = TH + 1, PW = TW + 1, PLANE = PH * PW;      // 85 pixels per parity plane
+  static constexpr int DYP = TH * TW / 16;                           // 4 pieces per dy chunk image
+  static constexpr int XP = (4 * PLANE + 15) / 16;                   // 22 pieces per x chunk image (4 planes)
+  static constexpr int DYB = DYP * 1024, XB = XP * 1024;
+  static constexpr int STAGE = NOB * DYB + NCB * XB;
+  static constexpr int NPIECE = NOB * DYP + NCB * XP;
+  static constexpr int PR = (NPIECE + 7) / 8;
+  static constexpr int NST = 3;
+  static constexpr int LDS = NST * STAGE;
+  static constexpr int BO = 32 * NOB, BC = 32 * NCB;
+};
+
+template <int NOB, int NCB, int KS>
+__global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
+  typedef Wg3s2Cfg<NOB, NCB, KS> Cfg;
+  static_assert(NOB * NCB * KS * 2 == 8, "8 waves");
+  constexpr int TH = Cfg::TH, TW = Cfg::TW, PW = Cfg::PW, PLANE = Cfg::PLANE, PR = Cfg::PR;
+  constexpr int DYP = Cfg::DYP, XP = Cfg::XP, DYB = Cfg::DYB, XB = Cfg::XB, STAGE = Cfg::STAGE, NST = Cfg::NST;
+  constexpr int ROWS = TH / KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) bf16x4* tr_ptr_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int th = wave & 1;                                // tap half: 0 -> kernel rows 1,3 (plane a=0), 1 -> rows 0,2 (a=1)
+  const int ks = (wave >> 1) % KS, cb = (wave / (2 * KS)) % NCB, ob = wave / (2 * KS * NCB);
+  const int h = lane >> 5, l32 = lane & 31;
+  const int pairs = p.otiles * p.ctiles;
+  const int pair = blockIdx.x % pairs, g = blockIdx.x / pairs, G = gridDim.x / pairs;
+  const int o0 = (pair / p.ctiles) * Cfg::BO, c0 = (pair % p.ctiles) * Cfg::BC;
+  const int tilesX = (p.OW + TW - 1) / TW, tilesY = (p.OH + TH - 1) / TH;
+  const int tpi = tilesX * tilesY, ntiles = p.N * tpi;
+  const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
+  const unsigned char* __restrict__ dyg = (const unsigned char*)p.dy;
+  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
+
+  unsigned poff[PR];        // dy: from pixel (ty0, tx0); x: from input pixel (2*ty0 - 1, 2*tx0 - 1)
+  int pyx[PR];              // dy: local (y << 16 | x); x: input offset (dy+1 << 16 | dx+1) from that origin; y = 0x4000: zeros
+  int pdst[PR];
+  bool pisdy[PR];
+#pragma unroll
+  for (int r = 0; r < PR; ++r) {
+    int u = r * 8 + wave;
+    if (u >= Cfg::NPIECE) u -= Cfg::NPIECE;
+    const bool isdy = u < NOB * DYP;
+    const int v = isdy ? u : u - NOB * DYP;
+    const int chunk = isdy ? v / DYP : v / XP, grp = isdy ? v % DYP : v % XP;
+    const int lpx = grp * 16 + (lane >> 2), slot = lane & 3;
+    pisdy[r] = isdy;
+    pdst[r] = isdy ? chunk * DYB + grp * 1024 : NOB * DYB + chunk * XB + grp * 1024;
+    if (isdy) {
+      const int y = lpx / TW, x = lpx % TW;
+      const bool ok = o0 + chunk * 32 < p.Os;
+      poff[r] = (unsigned)((((y * p.OW + x) * p.Os) + o0 + chunk * 32) * 2 + slot * 16);
+      pyx[r] = ((ok ? y : 0x4000) << 16) | x;
+    } else {
+      const int plane = lpx / PLANE, rem = lpx % PLANE;
+      const int li = rem / PW, lj = rem % PW;
+      const int yy = 2 * li - (plane >> 1) + 1, xx = 2 * lj - (plane & 1) + 1;       // >= 0
+      const bool ok = c0 + chunk * 32 < p.Cs && lpx < 4 * PLANE;
+      poff[r] = (unsigned)((((yy * p.W + xx) * p.Cs) + c0 + chunk * 32) * 2 + slot * 16);
+      pyx[r] = ((ok ? yy : 0x4000) << 16) | xx;
+    }
+  }
+  auto tile_pos = [&](int t, int& img, int& ty0, int& tx0) {
+    img = t / tpi;
+    const int rem = t - img * tpi;
+    const int ty = rem / tilesX;
+    ty0 = ty * TH; tx0 = (rem - ty * tilesX) * TW;
+  };
+  auto issue_piece = [&](int r, int img, int ty0, int tx0, int stage) {
+    const int ly = pyx[r] >> 16, lx = pyx[r] & 0xffff;
+    const unsigned char* src;
+    if (pisdy[r]) {
+      const bool ok = ty0 + ly < p.OH && tx0 + lx < p.OW;
+      const unsigned char* base = dyg + ((size_t)((size_t)img * p.OH + ty0) * p.OW + tx0) * p.Os * 2;
+      src = ok ? base + poff[r] : zsrc;
+    } else {
+      const int iy = 2 * ty0 - 1 + ly, ix = 2 * tx0 - 1 + lx;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned char* base = xg + ((long)((long)img * p.H + 2 * ty0 - 1) * p.W + 2 * tx0 - 1) * p.Cs * 2;
+      src = ok ? base + poff[r] : zsrc;
+    }
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(smem + stage * STAGE + pdst[r]), 16, 0, 0);
+  };
+
+  f32x16 acc[8];            // local tap lt = u*4 + s: kernel row r = 2u + 1 - th, column s
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+  const int lterm = (8 * h + tq) * 64 + (16 * g16 + 4 * tp) * 2;
+  const int abase = ob * DYB + ks * TW * 64 + lterm;
+  const int bbase = NOB * DYB + cb * XB + (th * 2 * PLANE + ks * PW) * 64 + lterm;     // planes (a = th, b = 0..1)
+
+  int t = g;
+  {
+    int img, ty0, tx0;
+#pragma unroll
+    for (int pre = 0; pre < 2; ++pre) {
+      if (g + pre * G < ntiles) {
+        tile_pos(g + pre * G, img, ty0, tx0);
+#pragma unroll
+        for (int r = 0; r < PR; ++r) issue_piece(r, img, ty0, tx0, pre);
+      }
+    }
+  }
+  int stage = 0;
+  for (; t < ntiles; t += G) {
+    if (t + G < ntiles) wait_vmcnt<PR>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool more = t + 2 * G < ntiles;
+    int nimg = 0, nty0 = 0, ntx0 = 0;
+    if (more) tile_pos(t + 2 * G, nimg, nty0, ntx0);
+    const int nstage = stage + 2 >= NST ? stage + 2 - NST : stage + 2;
+    const unsigned char* sA = smem + stage * STAGE + abase;
+    const unsigned char* sB = smem + stage * STAGE + bbase;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+      const int y = j * KS;                                           // + ks (in the bases)
+      bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW) * 64));
+      bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW + 4) * 64));
+      const bf16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+      for (int lt = 0; lt < 8; ++lt) {
+        const int u = lt >> 2, s = lt & 3;
+        const int b = (s + 1) & 1;                                    // column parity plane
+        const int hp = b * PLANE + (y + u) * PW + (s >> 1);
+        bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + hp * 64));
+        bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64));
+        const bf16x8 bf = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+        acc[lt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf, acc[lt], 0, 0, 0);
+      }
+      if (more) {
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+          if (r * ROWS / PR == j) issue_piece(r, nimg, nty0, ntx0, nstage);
+      }
+    }
+    stage = stage + 1 == NST ? 0 : stage + 1;
+  }
+
+  const size_t rowstride = (size_t)16 * p.Cpad;
+  const int c = c0 + cb * 32 + l32;
+  if (c < p.Cpad) {
+#pragma unroll
+    for (int lt = 0; lt < 8; ++lt) {
+      const int tap = (2 * (lt >> 2) + 1 - th) * 4 + (lt & 3);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (o < p.Opad) unsafeAtomicAdd(&p.dw[(size_t)o * rowstride + (size_t)tap * p.Cpad + c], acc[lt][r]);
+      }
+    }
+  }
+}
+
+template <int NOB, int NCB, int KS>
+static int launch_wgrad3s2(const WgradParams& p0, hipStream_t st) {
+  typedef Wg3s2Cfg<NOB, NCB, KS> Cfg;
+  WgradParams p = p0;
+  p.otiles = (int)vg_ceil_div(p.Opad, Cfg::BO);
+  p.ctiles = (int)vg_ceil_div(p.Cpad, Cfg::BC);
+  const int pairs = p.otiles * p.ctiles;
+  const int ntiles = p.N * (int)vg_ceil_div(p.OH, Cfg::TH) * (int)vg_ceil_div(p.OW, Cfg::TW);
+  int G = (int)vg_ceil_div(256, pairs);
+  if (G > ntiles) G = ntiles;
+  auto kern = wgrad3s2_kernel<NOB, NCB, KS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(pairs * G), dim3(512), Cfg::LDS, st, p);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
 static int g_wgrad_kernel = 3;
 extern "C" void vg_set_wgrad_kernel(int version) { g_wgrad_kernel = version; }
 
 // returns true when the spatial-tile kernel took the launch
 static bool dispatch_wgrad3(const WgradParams& p, int R, int S, int dtype, hipStream_t st, int* rc) {
-  if (g_wgrad_kernel < 3 || dtype != VG_BF16 || p.in_s != 1 || R != 3 || S != 3 || p.OW < 24) return false;
-  if ((size_t)p.N * p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31) * 2 || (size_t)p.N * p.OH * p.OW * p.Os * 2 >= ((size_t)1 << 32))
-    return false;                                            // 32-bit piece offsets inside one image are all we need, keep it simple
+  if (g_wgrad_kernel < 3 || dtype != VG_BF16) return false;
+  if ((size_t)p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31) || (size_t)p.OH * p.OW * p.Os * 2 >= ((size_t)1 << 31))
+    return false;                                            // piece offsets are 32-bit inside one image
+  if (p.in_s == 2 && R == 4 && S == 4 && p.dy_[0] == -1 && p.dx_[0] == -1 && p.OW >= 8) {
+    if (p.Opad >= 128) *rc = launch_wgrad3s2<4, 1, 1>(p, st);
+    else if (p.Opad > 32) *rc = launch_wgrad3s2<2, 1, 2>(p, st);
+    else *rc = launch_wgrad3s2<1, 1, 4>(p, st);
+    return true;
+  }
+  if (p.in_s != 1 || R != 3 || S != 3 || p.OW < 24) return false;
   if (p.Opad <= 32) *rc = launch_wgrad3<1, 2, 4>(p, st);
   else if (p.Cpad <= 32) *rc = launch_wgrad3<2, 1, 4>(p, st);
   else *rc = launch_wgrad3<2, 2, 2>(p, st);
