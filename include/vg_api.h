@@ -80,13 +80,16 @@ int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t,
                   double* stats, int act, int accumulate, void* stream);
 /* dW[O][I][R][S] (f32, OIHW) = sum over pixels of dy ⊗ im2col(x).  `ws` is f32 scratch of
  * vg_conv_wgrad_ws_bytes(d) bytes.  Serves both Conv2d.weight.grad and ConvTranspose2d.weight.grad
- * (roles of x / dy swapped by the caller). */
+ * (roles of x / dy swapped by the caller).  accumulate != 0: dW += (the gradient goes straight into a
+ * parameter's .grad, which the training step zeroed: a parameter used twice per backward sums up). */
 size_t vg_conv_wgrad_ws_bytes(const vg_conv_desc* d);
-int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, void* stream);
+int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, int accumulate,
+                  void* stream);
 
 /* per-channel column sum: out[c] (f32) = sum_m a[m][c], c < c_valid.  bias gradients.
- * ws: VG_STATS_REPLICAS*cs f64 of scratch. */
-int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws, void* stream);
+ * ws: VG_STATS_REPLICAS*cs f64 of scratch.  accumulate != 0: out[c] +=. */
+int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws, int accumulate,
+                   void* stream);
 
 /* ---- layout ------------------------------------------------------------------------------ */
 /* NCHW f32 [n][c][h][w]  <->  NHWC `dtype` [n][h][w][cs] (channels >= c written as zero). */
@@ -121,11 +124,11 @@ int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float
  * dgamma = sum_dzxhat, dbeta = sum_dz (f32 [c]). */
 /* NOTE: `sums` must be followed by 3*cpad f32 of scratch (coefficients), i.e. allocate
  * VG_STATS_REPLICAS*2*cpad f64 + 3*cpad f32. */
-/* y may be NULL under the same conditions as in vg_bn_bwd_reduce. */
+/* y may be NULL under the same conditions as in vg_bn_bwd_reduce.  accumulate != 0: dgamma, dbeta +=. */
 int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                     const float* scale, const float* shift, const float* gamma, const double* sums, void* dx,
-                    void* dres, float* dgamma, float* dbeta, int64_t rows, int cs, int c, int cpad, int act,
-                    int dtype, void* stream);
+                    void* dres, float* dgamma, float* dbeta, int accumulate, int64_t rows, int cs, int c, int cpad,
+                    int act, int dtype, void* stream);
 /* Plain elementwise activation backward (no BN): dx = dout * act'(y). */
 int vg_act_bwd(const void* dout, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
 /* a += b (elementwise, `dtype`): gradient fan-in of the residual skip. */

@@ -28,7 +28,7 @@ def run_wgrad(lib, d, x, gy, mode):
     lib.vg_set_wgrad_kernel(mode)
     ws = torch.empty(lib.vg_conv_wgrad_ws_bytes(C.byref(d)) // 4, dtype=torch.float32, device="cuda")
     dw = torch.full((d.co, d.ci, d.r, d.s), float("nan"), dtype=torch.float32, device="cuda")
-    L.check(lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), L.stream()), "wgrad")
+    L.check(lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, L.stream()), "wgrad")
     torch.cuda.synchronize()
     return dw
 

@@ -74,7 +74,7 @@ def check_conv(n, h, w, ci, co, k, stride, pad, dtype, seed=0, verbose=True):
                               L.stream()), "dgrad")
     ws = torch.empty(lib.vg_conv_wgrad_ws_bytes(C.byref(d)) // 4, dtype=torch.float32, device="cuda")
     dw = torch.full((co, ci, k, k), float("nan"), dtype=torch.float32, device="cuda")
-    L.check(lib.vg_conv_wgrad(C.byref(d), xd.data_ptr(), gyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), L.stream()), "wgrad")
+    L.check(lib.vg_conv_wgrad(C.byref(d), xd.data_ptr(), gyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, L.stream()), "wgrad")
     torch.cuda.synchronize()
     res = {}
     yc = from_nhwc(y, co)

@@ -15,7 +15,7 @@ def run(n, h, w, ci, co, k, stride, pad, iters=5):
     res = []
     for mode in (1, 3):
         lib.vg_set_wgrad_kernel(mode)
-        fn = lambda: lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), L.stream())
+        fn = lambda: lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, L.stream())
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

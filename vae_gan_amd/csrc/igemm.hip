@@ -1867,7 +1867,7 @@ template <typename T> static int dispatch_wgrad(const WgradParams& p, hipStream_
 }
 
 __global__ void wgrad_unpack_kernel(const float* __restrict__ packed, float* __restrict__ dw, int O, int I, int RS,
-                                    int Cpad) {
+                                    int Cpad, int accumulate) {
   // dw[o][i][rs] = packed[o][rs][i]
   const long total = (long)O * I * RS;
   for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -1875,7 +1875,8 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ packed, float* __r
     long oi = t / RS;
     int i = (int)(oi % I);
     int o = (int)(oi / I);
-    dw[t] = packed[((size_t)o * RS + rs) * Cpad + i];
+    const float v = packed[((size_t)o * RS + rs) * Cpad + i];
+    dw[t] = accumulate ? dw[t] + v : v;
   }
 }
 
@@ -1886,7 +1887,7 @@ extern "C" size_t vg_conv_wgrad_ws_bytes(const vg_conv_desc* d) {
 }
 
 extern "C" int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws,
-                             void* stream) {
+                             int accumulate, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   VG_REQUIRE(x && dy && dw_oihw && ws, "conv_wgrad: null pointer");
@@ -1909,7 +1910,7 @@ extern "C" int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* d
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw_oihw, d->co, d->ci,
-                     d->r * d->s, p.Cpad);
+                     d->r * d->s, p.Cpad, accumulate);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

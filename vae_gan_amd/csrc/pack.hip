@@ -198,16 +198,16 @@ template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(
 }
 
 __global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n, double scale, int replicas,
-                           int stride) {
+                           int stride, int accumulate) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double t = 0.0;
   for (int r = 0; r < replicas; ++r) t += src[(size_t)r * stride + i];
-  dst[i] = (float)(t * scale);
+  dst[i] = accumulate ? dst[i] + (float)(t * scale) : (float)(t * scale);
 }
 
 extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws,
-                              void* stream) {
+                              int accumulate, void* stream) {
   VG_REQUIRE(a && out && ws && rows > 0 && cs > 0 && c_valid <= cs, "channel_sum: bad arguments");
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_sum: channel stride %d unsupported", cs);
@@ -221,14 +221,14 @@ extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, 
   else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws);
   VG_LAUNCH_CHECK();
   hipLaunchKernelGGL(d2f_kernel, dim3((c_valid + 255) / 256), dim3(256), 0, st, (const double*)ws, out, c_valid, 1.0,
-                     VG_STATS_REPLICAS, cs);
+                     VG_STATS_REPLICAS, cs, accumulate);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
 
 extern "C" int vg_scalar_finish(const double* src, double scale, float* dst, void* stream) {
   VG_REQUIRE(src && dst, "scalar_finish: null pointer");
-  hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, dst, 1, scale, 1, 0);
+  hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, dst, 1, scale, 1, 0, 0);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

@@ -47,8 +47,8 @@ SIGNATURES = {
     "vg_conv_fwd_splitk": (_I, [_DP, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vg_conv_dgrad": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vg_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
-    "vg_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _P]),
-    "vg_channel_sum": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
+    "vg_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
+    "vg_channel_sum": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _P]),
     "vg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_avgpool2_nchw": (_I, [_P, _P, _L, _I, _I, _P]),
@@ -56,7 +56,7 @@ SIGNATURES = {
     "vg_channel_stats": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
-    "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P]),
     "vg_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "vg_add_inplace": (_I, [_P, _P, _L, _I, _P]),
     "vg_vq_assign": (_I, [_P, _P, _L, _I, _I, _P, _P]),

@@ -165,8 +165,75 @@ def _conv_desc(n, h, w, ci, co, k, stride, pad, xcs, ycs, dt) -> L.ConvDesc:
                       dtype=L.vg_dtype(dt))
 
 
+class _ZeroArena:
+    """Zeroed f64 scratch for one training step.  Every BatchNorm forward/backward and bias gradient needs a small
+    zeroed f64 accumulator; as separate torch.zeros calls those are ~130 fill kernels per step.  Inside
+    ``step_scope()`` they are slices of one buffer that is cleared by ONE fill at the start of the step."""
+
+    def __init__(self):
+        self.buf, self.off, self.want = None, 0, 1 << 20
+
+    def begin(self, device):
+        if self.buf is None or self.buf.numel() < self.want or self.buf.device != device:
+            self.buf = torch.empty(self.want, dtype=torch.float64, device=device)
+            self.buf.zero_()
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+    def take(self, n: int):
+        n_al = (n + 31) // 32 * 32
+        if self.buf is None or self.off + n_al > self.buf.numel():
+            self.want = max(self.want, 2 * (self.off + n_al))     # grow at the next step
+            return None
+        out = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return out
+
+
+_ARENA = _ZeroArena()
+_STEP = [False]     # inside step_scope(): arena slices instead of torch.zeros, gradients written straight into .grad
+
+
+class step_scope:
+    """Context of one optimizer phase of a training step (forward + backward).  Enables (a) the zero arena and
+    (b) direct gradient accumulation: weight / bias / BatchNorm gradients are added into the parameter's existing
+    ``.grad`` (FlatAdam's flat buffer, zeroed by ``zero_grad``) by the producing kernel instead of being returned
+    to autograd, which would add them with one elementwise kernel per parameter."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        _ARENA.begin(self.device)
+        _STEP[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _STEP[0] = False
+        return False
+
+
+def _zeros_f64(n: int, device) -> torch.Tensor:
+    if _STEP[0]:
+        t = _ARENA.take(n)
+        if t is not None:
+            return t
+    return torch.zeros(n, dtype=torch.float64, device=device)
+
+
+def _grad_slot(p) -> Optional[torch.Tensor]:
+    """The tensor a kernel may accumulate ``p``'s gradient into, or None (plain autograd path)."""
+    if not _STEP[0] or p is None:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
 def _stats_buf(npad: int, device) -> torch.Tensor:
-    return torch.zeros(L.STATS_REPLICAS * 2 * npad, dtype=torch.float64, device=device)
+    return _zeros_f64(L.STATS_REPLICAS * 2 * npad, device)
 
 
 def _act_bwd(g: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
@@ -175,23 +242,28 @@ def _act_bwd(g: torch.Tensor, y: torch.Tensor, act: int) -> torch.Tensor:
     return out
 
 
-def _channel_sum(t: torch.Tensor, c: int) -> torch.Tensor:
+def _channel_sum(t: torch.Tensor, c: int, param=None) -> Optional[torch.Tensor]:
+    """Per-channel sum (bias gradient).  Returns None when it was accumulated straight into ``param.grad``."""
     cs = t.shape[-1]
     rows = t.numel() // cs
-    out = torch.empty(c, dtype=torch.float32, device=t.device)
+    slot = _grad_slot(param)
+    out = slot if slot is not None else torch.empty(c, dtype=torch.float32, device=t.device)
     ws = torch.empty(L.STATS_REPLICAS * cs, dtype=torch.float64, device=t.device)
-    L.check(L.load().vg_channel_sum(t.data_ptr(), rows, cs, c, L.vg_dtype(t.dtype), out.data_ptr(), ws.data_ptr(), L.stream()), "channel_sum")
-    return out
+    L.check(L.load().vg_channel_sum(t.data_ptr(), rows, cs, c, L.vg_dtype(t.dtype), out.data_ptr(), ws.data_ptr(),
+                                    int(slot is not None), L.stream()), "channel_sum")
+    return None if slot is not None else out
 
 
-def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape) -> torch.Tensor:
+def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape, param=None) -> Optional[torch.Tensor]:
+    """Weight gradient (OIHW f32).  Returns None when it was accumulated straight into ``param.grad``."""
     lib = L.load()
     ws = torch.empty(lib.vg_conv_wgrad_ws_bytes(C.byref(desc)) // 4, dtype=torch.float32, device=x.device)
-    dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+    slot = _grad_slot(param)
+    dw = slot if slot is not None else torch.empty(wshape, dtype=torch.float32, device=x.device)
     L.check(_timed("wgrad(memset+wgrad_kernel+unpack)", _conv_flops(desc),
                    lambda: lib.vg_conv_wgrad(C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                                             L.stream())), "conv_wgrad")
-    return dw
+                                             int(slot is not None), L.stream())), "conv_wgrad")
+    return None if slot is not None else dw
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -214,6 +286,7 @@ class Conv2dFn(torch.autograd.Function):
                        lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(),
                                                L.ptr(stats), act, 0, L.stream())), "conv_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -235,9 +308,9 @@ class Conv2dFn(torch.autograd.Function):
                            lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
                                                      L.ACT_NONE, 0, L.stream())), "conv_dgrad")
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(d, x, gy, weight.shape)
+            dw = _wgrad(d, x, gy, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _channel_sum(gy, d.co)
+            db = _channel_sum(gy, d.co, ctx.bparam)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -264,6 +337,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
                        lambda: lib.vg_conv_dgrad(C.byref(d), x.data_ptr(), wpt.data_ptr(), L.ptr(bias), y.data_ptr(),
                                                  L.ptr(stats), act, 0, L.stream())), "convT_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -285,9 +359,9 @@ class ConvTranspose2dFn(torch.autograd.Function):
                            lambda: lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None,
                                                    L.ACT_NONE, 0, L.stream())), "convT_dgrad")
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(d, gy, x, weight.shape)
+            dw = _wgrad(d, gy, x, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _channel_sum(gy, d.ci)
+            db = _channel_sum(gy, d.ci, ctx.bparam)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -323,6 +397,7 @@ class BNActFn(torch.autograd.Function):
         L.check(lib.vg_bn_act_fwd(x.data_ptr(), L.ptr(res), y.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), rows, cs, c,
                                   act, L.vg_dtype(x.dtype), L.stream()), "bn_act_fwd")
         ctx.c, ctx.cpad, ctx.act, ctx.has_res = c, cpad, act, res is not None
+        ctx.gparam, ctx.bparam = gamma, beta
         ctx.save_for_backward(x, y, vec, gamma)
         return y
 
@@ -334,7 +409,7 @@ class BNActFn(torch.autograd.Function):
         cs = x.shape[-1]
         rows = x.numel() // cs
         c, cpad = ctx.c, ctx.cpad
-        sums = torch.zeros(L.STATS_REPLICAS * 2 * cpad + 2 * cpad, dtype=torch.float64, device=x.device)
+        sums = _zeros_f64(L.STATS_REPLICAS * 2 * cpad + 2 * cpad, x.device)
         dtc = L.vg_dtype(x.dtype)
         # without a residual the LeakyReLU mask is recomputed from x (one tensor read less per pass)
         yp = None if (not ctx.has_res and ctx.act in (L.ACT_NONE, L.ACT_LRELU)) else y.data_ptr()
@@ -343,11 +418,15 @@ class BNActFn(torch.autograd.Function):
                                      L.stream()), "bn_bwd_reduce")
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        dgb = torch.empty(2, c, dtype=torch.float32, device=x.device)
+        gslot, bslot = _grad_slot(ctx.gparam), _grad_slot(ctx.bparam)
+        direct = gslot is not None and bslot is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+        dgb = (gslot, bslot) if direct else torch.empty(2, c, dtype=torch.float32, device=x.device)
         L.check(lib.vg_bn_bwd_apply(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
                                     vec[2].data_ptr(), vec[3].data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(),
                                     L.ptr(dres), dgb[0].data_ptr(),
-                                    dgb[1].data_ptr(), rows, cs, c, cpad, ctx.act, dtc, L.stream()), "bn_bwd_apply")
+                                    dgb[1].data_ptr(), int(direct), rows, cs, c, cpad, ctx.act, dtc, L.stream()), "bn_bwd_apply")
+        if direct:
+            return dx, None, None, None, dres, None, None, None, None, None, None, None
         return dx, None, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
 
 

@@ -11,6 +11,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .optim import FlatAdam, StepLR
 
 
@@ -68,19 +69,22 @@ def vq_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[
     """vq_vae_gan/main.py:75-111.  Returns (d_loss_dict, g_loss_dict, indices) with device scalars."""
     # ---- discriminator step
     opt_d.zero_grad()
-    recon, _, _, vq_loss, _ = model(images)
-    disc_real = model.discriminator(images)
-    disc_fake = model.discriminator(recon.detach())
-    d_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=False)
-    d_loss['total'].backward()
+    with ops.step_scope(images.device):
+        with torch.no_grad():      # the D loss only sees recon.detach(): no tape for the generator pass
+            recon, _, _, vq_loss, _ = model(images)
+        disc_real = model.discriminator(images)
+        disc_fake = model.discriminator(recon)
+        d_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=False)
+        d_loss['total'].backward()
     opt_d.step(dp.reduce(opt_d) if dp else 1.0)
     # ---- generator step (second full forward: EMA + BatchNorm statistics update again)
     opt_g.zero_grad()
-    recon, _, _, vq_loss, indices = model(images)
-    with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
-        disc_fake = model.discriminator(recon)
-        g_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=True)
-        g_loss['total'].backward()
+    with ops.step_scope(images.device):
+        recon, _, _, vq_loss, indices = model(images)
+        with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
+            disc_fake = model.discriminator(recon)
+            g_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=True)
+            g_loss['total'].backward()
     opt_g.step(dp.reduce(opt_g) if dp else 1.0)
     return d_loss, g_loss, indices
 
@@ -91,17 +95,18 @@ def beta_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optiona
     only re-runs D(recon).  With the reference's shapes loss_function raises (128 vs 256) unless the model was
     built with recon_target_policy='area' (shim D1)."""
     opt_d.zero_grad()
-    recon, _, mu, logvar = model(images, eps)
-    disc_real = model.discriminator(images)
-    disc_fake = model.discriminator(recon.detach())
-    d_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=False)
-    d_loss['total'].backward()
-    opt_d.step(dp.reduce(opt_d) if dp else 1.0)
-    opt_g.zero_grad()
-    with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
-        disc_fake = model.discriminator(recon)
-        g_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=True)
-        g_loss['total'].backward()
+    with ops.step_scope(images.device):
+        recon, _, mu, logvar = model(images, eps)
+        disc_real = model.discriminator(images)
+        disc_fake = model.discriminator(recon.detach())
+        d_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=False)
+        d_loss['total'].backward()
+        opt_d.step(dp.reduce(opt_d) if dp else 1.0)
+        opt_g.zero_grad()
+        with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
+            disc_fake = model.discriminator(recon)
+            g_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=True)
+            g_loss['total'].backward()
     opt_g.step(dp.reduce(opt_g) if dp else 1.0)
     return d_loss, g_loss
 
@@ -112,17 +117,20 @@ def hier_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optiona
     three levels in both).  Needs hier_decoder_policy='nearest' + recon_target_policy='area' (shims D2 + D1): with the
     reference's own composition the decoder raises."""
     opt_d.zero_grad()
-    recon, _, mu_list, logvar_list = model(images, eps_lists[0])
-    disc_real = model.discriminator(images)
-    disc_fake = model.discriminator(recon.detach())
-    d_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=False)
-    d_loss['total'].backward()
+    with ops.step_scope(images.device):
+        with torch.no_grad():      # the D loss only sees recon.detach(): no tape for the generator pass
+            recon, _, mu_list, logvar_list = model(images, eps_lists[0])
+        disc_real = model.discriminator(images)
+        disc_fake = model.discriminator(recon)
+        d_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=False)
+        d_loss['total'].backward()
     opt_d.step(dp.reduce(opt_d) if dp else 1.0)
     opt_g.zero_grad()
-    recon, _, mu_list, logvar_list = model(images, eps_lists[1])
-    with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
-        disc_fake = model.discriminator(recon)
-        g_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=True)
-        g_loss['total'].backward()
+    with ops.step_scope(images.device):
+        recon, _, mu_list, logvar_list = model(images, eps_lists[1])
+        with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
+            disc_fake = model.discriminator(recon)
+            g_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=True)
+            g_loss['total'].backward()
     opt_g.step(dp.reduce(opt_g) if dp else 1.0)
     return d_loss, g_loss
