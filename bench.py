@@ -8,13 +8,15 @@ synthetic RGB) on N MI355X of one node.
            --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line: whole-job train images/s (weak scaling: 64 images per GPU), plus
- * "roofline": algorithmic FLOPs of the dominant kernel (the 128x128-tile bf16 implicit-GEMM conv)
-   divided by its HIP-event-timed launch durations inside the timed region, against the 2.5 PFLOP/s
-   dense bf16 MFMA peak;
+ * "roofline": algorithmic FLOPs of the dominant kernel (the gather-GEMM conv variant with the largest total
+   time in the timed region; the library reports which variant each launch used) divided by its
+   HIP-event-timed launch durations, against the 2.5 PFLOP/s dense bf16 MFMA peak; "traffic" = its
+   HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json);
  * "cpu_baseline": the CPU oracle's train step (oracle/vaegan_oracle.py, a port of the reference
    step) timed on this host on a bounded sample (N=1, rank 0 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -56,6 +58,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-shapes", action="store_true", help="key the live kernel timings by layer shape too")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,7 +98,7 @@ def main():
         vq_train_step(model, images, opt_g, opt_d, dp)
     prof = None
     if not args.no_kernel_timing:
-        prof = ops.KernelProfile()
+        prof = ops.KernelProfile(shapes=args.kernel_shapes)
         ops.PROFILE[0] = prof
     barrier()
     t0 = time.perf_counter()
@@ -121,8 +124,16 @@ def main():
                                  "tflops": d["flops"] / d["ms"] / 1e9}
             dom = max((n for n in summ if n.startswith("igemm")), key=lambda n: summ[n]["ms"])
             ach = summ[dom]["flops"] / summ[dom]["ms"] / 1e9
+            # HBM-side traffic of that kernel per launch: measured in separate rocprofv3 --pmc passes over this same
+            # command (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; profiles/make_pmc_summary.py)
+            traffic, tsrc = None, None
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                ent = json.load(open(f)).get(dom)
+                if ent:
+                    traffic, tsrc = ent["traffic_bytes_per_launch"], os.path.basename(f)
+                    break
             roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                    "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
                     "launches_per_step": summ[dom]["launches"] / args.steps,
                     "avg_launch_ms": summ[dom]["ms"] / summ[dom]["launches"],
                     "avg_launch_gflop": summ[dom]["flops"] / summ[dom]["launches"] / 1e9}

@@ -34,16 +34,19 @@ class KernelProfile:
     """Optional per-launch HIP-event timing of the conv kernels (bench.py's live roofline numbers).
     Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
 
-    def __init__(self):
+    def __init__(self, shapes: bool = False):
         self.records = []     # (kernel name, algorithmic flops, start event, end event)
+        self.shapes = shapes  # key the summary by layer shape as well (diagnostics)
 
-    def launch(self, name, flops, fn):
+    def launch(self, name, flops, fn, tag=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn()
         e1.record()
         if name is None:      # gather-GEMM launch: ask the library which kernel variant it dispatched
             name = L.load().vg_last_conv_kernel().decode()
+        if self.shapes and tag is not None:
+            name += " " + tag
         self.records.append((name, flops, e0, e1))
         return rc
 
@@ -61,13 +64,17 @@ class KernelProfile:
 PROFILE = [None]   # set PROFILE[0] = KernelProfile() to time conv launches
 
 
+def _shape_tag(kind, d) -> str:
+    return f"{kind} n{d.n} {d.h}x{d.w} {d.ci}->{d.co} k{d.r}s{d.stride}"
+
+
 def _conv_flops(d) -> float:
     return 2.0 * d.n * d.oh * d.ow * d.co * d.ci * d.r * d.s
 
 
-def _timed(name, flops, fn):
+def _timed(name, flops, fn, tag=None):
     prof = PROFILE[0]
-    return fn() if prof is None else prof.launch(name, flops, fn)
+    return fn() if prof is None else prof.launch(name, flops, fn, tag)
 
 
 def _npad(n: int) -> int:
@@ -262,7 +269,7 @@ def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape, param=No
     dw = slot if slot is not None else torch.empty(wshape, dtype=torch.float32, device=x.device)
     L.check(_timed("wgrad(memset+wgrad_kernel+unpack)", _conv_flops(desc),
                    lambda: lib.vg_conv_wgrad(C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(),
-                                             int(slot is not None), L.stream())), "conv_wgrad")
+                                             int(slot is not None), L.stream()), _shape_tag("", desc)), "conv_wgrad")
     return None if slot is not None else dw
 
 
@@ -284,7 +291,7 @@ class Conv2dFn(torch.autograd.Function):
         lib = L.load()
         L.check(_timed(None, _conv_flops(d),
                        lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(),
-                                               L.ptr(stats), act, 0, L.stream())), "conv_fwd")
+                                               L.ptr(stats), act, 0, L.stream()), _shape_tag("fwd", d)), "conv_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
@@ -306,7 +313,7 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             L.check(_timed(None, _conv_flops(d),
                            lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
-                                                     L.ACT_NONE, 0, L.stream())), "conv_dgrad")
+                                                     L.ACT_NONE, 0, L.stream()), _shape_tag("dgrad", d)), "conv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, x, gy, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -335,7 +342,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         lib = L.load()
         L.check(_timed(None, _conv_flops(d),
                        lambda: lib.vg_conv_dgrad(C.byref(d), x.data_ptr(), wpt.data_ptr(), L.ptr(bias), y.data_ptr(),
-                                                 L.ptr(stats), act, 0, L.stream())), "convT_fwd")
+                                                 L.ptr(stats), act, 0, L.stream()), _shape_tag("convT", d)), "convT_fwd")
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
@@ -357,7 +364,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             L.check(_timed(None, _conv_flops(d),
                            lambda: lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None,
-                                                   L.ACT_NONE, 0, L.stream())), "convT_dgrad")
+                                                   L.ACT_NONE, 0, L.stream()), _shape_tag("convT_dgrad", d)), "convT_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, gy, x, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2]:
