@@ -1005,7 +1005,10 @@ static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
 static int g_conv_kernel = 3;
 template <typename T, int R, int S> static int dispatch_igemm3_rs(const IgemmParams& p, hipStream_t st, bool* handled) {
   if (p.Npad % 256 == 0) return launch_igemm3<T, 4, 2, 2, 4, R, S>(p, st, handled);   // 8x32 px x 256 ch
-  if (p.Npad == 128) return launch_igemm3<T, 4, 2, 4, 2, R, S>(p, st, handled);       // 16x32 px x 128 ch
+  if (p.Npad == 128) {
+    if constexpr (Igemm3Cfg<T, 4, 2, 4, 2, R, S>::FITS) return launch_igemm3<T, 4, 2, 4, 2, R, S>(p, st, handled);   // 16x32 px x 128 ch
+    else return launch_igemm3<T, 2, 2, 4, 2, R, S>(p, st, handled);               // 8x32 px x 128 ch (three halo buffers fit)
+  }
   if (p.Npad == 64) return launch_igemm3<T, 2, 2, 8, 1, R, S>(p, st, handled);        // 16x32 px x 64 ch
   return VG_OK;
 }
