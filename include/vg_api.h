@@ -102,11 +102,13 @@ int vg_avgpool2_nchw(const float* src, float* dst, int64_t planes, int h, int w,
 
 /* ---- BatchNorm (training mode) + LeakyReLU(0.2) + residual ---------------------------------- */
 /* From the f64 stats of vg_conv_fwd: mean/invstd (biased var, eps), affine scale/shift, and the
- * running-stat update with momentum (unbiased var) + num_batches_tracked += 1.
+ * running-stat update with momentum (unbiased var) + num_batches_tracked += 1, applied `updates` times
+ * (updates = 2 stands for the two bit-identical encoder forwards of one VQ / hierarchical iteration,
+ * vq_vae_gan/main.py:78,99, of which only one is executed).
  * nn.BatchNorm2d training forward (every <arch>/model.py; e.g. vq_vae_gan/model.py:18-19,147,154). */
 int vg_bn_finalize(const double* stats, int c, int cpad, int64_t count, const float* gamma, const float* beta,
                    float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches,
-                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+                   int updates, float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* stats[VG_STATS_REPLICAS][2][cpad] (f64, zeroed by caller) += per-channel sum / sum of squares of x:
  * for a BatchNorm whose input is not a conv output (beta_vae_gans/model.py:117). */
 int vg_channel_stats(const void* x, double* stats, int64_t rows, int cs, int c, int cpad, int dtype, void* stream);

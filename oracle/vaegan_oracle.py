@@ -387,6 +387,78 @@ def hier_discriminator(sd: SD, x, num_hierarchies=3, train=True):
 
 
 # --------------------------------------------------------------------------------------
+# whole steps of the two architectures whose reference step raises (documented shims D1, D2)
+# --------------------------------------------------------------------------------------
+BETA_DEFAULT_CFG = dict(beta=1.0, lambda_adv=0.1)
+HIER_DEFAULT_CFG = dict(beta=1.0, lambda_adv=0.1, level_weights=[1.0, 0.75, 0.5], num_hierarchies=3)
+
+
+def _vae_g_loss(target, recon, kl, d_fake, beta, lambda_adv):
+    """beta_vae_gans/model.py:255-266 == hierarchical_vae_gan/model.py:403-417."""
+    recon_loss = F.mse_loss(recon, target)
+    adv = -d_fake.mean()
+    return recon_loss + beta * kl + lambda_adv * adv, recon_loss, adv
+
+
+def beta_train_step(sd: SD, images, eps, cfg, opt, lr_g=1e-4, lr_d=5e-5):
+    """One iteration of beta_vae_gans/main.py:75-108: ONE generator forward; the G step reuses
+    recon/mu/logvar and re-runs D(recon) with the updated D (BatchNorm statistics of D update a third
+    time).  NON-REFERENCE shim D1: the reconstruction is 128x128, so the MSE target is
+    avg_pool2d(original, 2) — with the original itself model.py:255 raises."""
+    gn, dn = g_param_names(sd), d_param_names(sd)
+    _set_requires(sd, gn, True)
+    _set_requires(sd, dn, True)
+    target = F.avg_pool2d(images, 2)
+    mu, logvar = beta_encoder(sd, images)
+    recon = beta_decoder(sd, reparameterize(mu, logvar, eps))
+    d_real = patch_discriminator(sd, images)
+    d_fake = patch_discriminator(sd, recon.detach())
+    d_loss = hinge_d_loss(d_real, d_fake)
+    grads = torch.autograd.grad(d_loss, [sd[k] for k in dn])
+    adam_step([sd[k] for k in dn], grads, opt["d"], lr_d)
+    d_fake = patch_discriminator(sd, recon)
+    kl = kl_loss(mu, logvar)
+    g_loss, recon_loss, adv = _vae_g_loss(target, recon, kl, d_fake, cfg["beta"], cfg["lambda_adv"])
+    grads = torch.autograd.grad(g_loss, [sd[k] for k in gn], allow_unused=True)
+    adam_step([sd[k] for k in gn], grads, opt["g"], lr_g)
+    return {"d_loss": d_loss.item(), "g_loss": g_loss.item(), "recon": recon_loss.item(), "kl": kl.item(),
+            "adv": adv.item(), "recon_img": recon.detach()}
+
+
+def hier_train_step(sd: SD, images, eps_pair, cfg, opt, lr_g=1e-4, lr_d=5e-5):
+    """One iteration of hierarchical_vae_gan/main.py:75-111: two generator forwards, each drawing fresh
+    N(0,1) noise per level (``eps_pair`` = [draws of forward 1, draws of forward 2], level order 0,1,2).
+    NON-REFERENCE shims: D2 (decoder sub-blocks chained with nearest x2 upsampling, model.py:261 raises)
+    and D1 (target = avg_pool2d(original, 2): the reconstruction has half the input size)."""
+    gn, dn = g_param_names(sd), d_param_names(sd)
+    _set_requires(sd, gn, True)
+    _set_requires(sd, dn, True)
+    nh, w = cfg["num_hierarchies"], cfg["level_weights"]
+    target = F.avg_pool2d(images, 2)
+
+    def generator(eps_list):
+        mus, lvs = hier_encoder(sd, images, nh)
+        zs = [reparameterize(m, v, e) for m, v, e in zip(mus, lvs, eps_list)]
+        return hier_decoder_nearest(sd, zs, nh), mus, lvs
+
+    recon, mus, lvs = generator(eps_pair[0])
+    d_real = hier_discriminator(sd, images, nh)
+    d_fake = hier_discriminator(sd, recon.detach(), nh)
+    d_loss = hinge_d_loss(d_real, d_fake)
+    d_kl = hier_kl_loss(mus, lvs, w).item()
+    grads = torch.autograd.grad(d_loss, [sd[k] for k in dn])
+    adam_step([sd[k] for k in dn], grads, opt["d"], lr_d)
+    recon, mus, lvs = generator(eps_pair[1])
+    d_fake = hier_discriminator(sd, recon, nh)
+    kl = hier_kl_loss(mus, lvs, w)
+    g_loss, recon_loss, adv = _vae_g_loss(target, recon, kl, d_fake, cfg["beta"], cfg["lambda_adv"])
+    grads = torch.autograd.grad(g_loss, [sd[k] for k in gn], allow_unused=True)
+    adam_step([sd[k] for k in gn], grads, opt["g"], lr_g)
+    return {"d_loss": d_loss.item(), "d_kl": d_kl, "g_loss": g_loss.item(), "recon": recon_loss.item(), "kl": kl.item(),
+            "adv": adv.item(), "recon_img": recon.detach()}
+
+
+# --------------------------------------------------------------------------------------
 # state_dict templates (key → zero tensor of the right shape/dtype); SURVEY.md §8(b) contract
 # --------------------------------------------------------------------------------------
 def _t_conv(t, p, cin, cout, k):

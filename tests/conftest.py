@@ -84,3 +84,32 @@ def check_digests(g, grads, rtol=2e-4, k=4.0, name_map=lambda n: n):
         n += 1
     assert n > 0
     return n
+
+
+# ---- whole-step goldens (vq_step_64 / beta_step_256 / hier_step_128) --------------------------
+def check_step(g, it, r, keys):
+    """Scalars + reconstruction of iteration ``it`` of a whole-step golden (r: name -> float / tensor)."""
+    # reference's own fp32 noise floor; from the second iteration on every scalar also inherits the
+    # perturbation of the whole reconstruction by Adam's lr*sign(g) on rounding-noise gradients
+    # (noise:it1_recon_img), of which one fp32-vs-fp64 pair per scalar is only a point sample
+    floor = 4 * float(g[f"noise:it{it}_recon_img"]) if it > 0 else 0.0
+    for k in keys:
+        ref = float(g[f"it{it}_{k}"])
+        tol = max(1e-4, 4 * float(g[f"noise:it{it}_{k}"]), floor)
+        # adv = -mean(D(fake)) is a mean of signed O(1) logits (cancellation): its scale is that of d_loss
+        scale = max(abs(ref), 1e-3, abs(float(g[f"it{it}_d_loss"])) if k == "adv" else 0.0)
+        if k == "adv" and it > 0:
+            tol = max(1e-4, floor)
+        assert abs(r[k] - ref) <= tol * scale, (it, k, r[k], ref, tol)
+    close_l2(r["recon_img"], g[f"it{it}_recon_img"], g[f"noise:it{it}_recon_img"], what="recon")
+
+
+def check_state(g, sd, last_noise):
+    """BatchNorm counters exactly, every other state_dict entry by the l2 of its digest."""
+    for key, ref in g.items():
+        if key.startswith("sd:"):
+            assert int(sd[key[3:]]) == int(ref), key
+        elif key.startswith("sdd:"):
+            k = key[4:]
+            d = digest(k, sd[k])
+            assert abs(d[0] - ref[0]) <= max(1e-4, 4 * last_noise) * max(ref[0], 1e-6), k

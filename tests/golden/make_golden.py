@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 from vae_gan_amd.testing import (fill_state_dict, synthetic_images, synthetic_eps,  # noqa: E402
-                                 cotangent, digest)
+                                 cotangent, digest, hier_step_eps)
 
 REF = os.environ.get("VG_REFERENCE", "/root/reference")
 
@@ -248,9 +248,143 @@ def g_hier_modules():
     _module_fwd_bwd("hier_output_conv", lambda: dec().output_conv, 0.5 * synthetic_eps((2, 64, 32, 32), 56), "output_conv.")
 
 
+# ----------------------------------------------------------------------------------------
+# Whole-step goldens for the two architectures whose reference step raises.
+# The REFERENCE modules and the REFERENCE loss_function do all the arithmetic; the harness only
+# (D1) hands loss_function the 2x2-area-downsampled original so that mse_loss is defined on the
+# 128x128 reconstruction, (D2) chains the reference decoder sub-blocks with nearest x2 upsampling
+# instead of the mis-indexed ConvTranspose list, and injects the N(0,1) draws of reparameterize.
+# ----------------------------------------------------------------------------------------
+class _InjectedNoise:
+    """Replace torch.randn_like by a queue of prepared draws (same values in the fp32 and fp64 runs)."""
+
+    def __init__(self, draws):
+        self.draws = list(draws)
+
+    def __enter__(self):
+        self.orig = torch.randn_like
+        torch.randn_like = lambda t, **kw: self.draws.pop(0).to(t.dtype)
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self.orig
+        assert not self.draws, "unused noise draws"
+        return False
+
+
+def _step_digest(out, out64, sd):
+    for k, v in list(out.items()):
+        if k.startswith("it") and not k.endswith("recon_img"):
+            out["noise:" + k] = abs(v - out64[k]) / max(abs(out64[k]), 1e-12)
+        if k.endswith("recon_img"):
+            out["noise:" + k] = rel_l2(v, out64[k])
+    for k, v in sd.items():
+        if v.dtype == torch.int64:
+            out["sd:" + k] = v.clone()
+        else:
+            out["sdd:" + k] = digest(k, v)
+    return out
+
+
+def _adam_pair(model, cfg):
+    og = torch.optim.Adam(list(model.encoder.parameters()) + list(model.decoder.parameters()), lr=cfg.lr,
+                          betas=(cfg.beta1, cfg.beta2))
+    od = torch.optim.Adam(model.discriminator.parameters(), lr=cfg.lr / 2, betas=(cfg.beta1, cfg.beta2))
+    return og, od
+
+
+def _beta_step_run(dtype, iters, images, eps):
+    """beta_vae_gans/main.py:75-108 around the reference model; D1: target = avg_pool2d(original, 2)."""
+    m = load_ref("beta_vae_gans", "model")
+    cfg = load_ref("beta_vae_gans", "config").Config()
+    model = filled(m.BetaVAEGAN(cfg)).to(dtype).train()
+    opt_g, opt_d = _adam_pair(model, cfg)
+    images = images.to(dtype)
+    target = F.avg_pool2d(images, 2)
+    out = {}
+    for it in range(iters):
+        opt_d.zero_grad()
+        with _InjectedNoise([eps[it]]):
+            recon, _, mu, logvar = model(images)
+        d_real = model.discriminator(images)
+        d_fake = model.discriminator(recon.detach())
+        dl = model.loss_function(target, recon, mu, logvar, d_real, d_fake, train_generator=False)
+        dl["total"].backward()
+        opt_d.step()
+        opt_g.zero_grad()
+        d_fake = model.discriminator(recon)
+        gl = model.loss_function(target, recon, mu, logvar, d_real, d_fake, train_generator=True)
+        gl["total"].backward()
+        opt_g.step()
+        out.update({f"it{it}_d_loss": dl["total"].item(), f"it{it}_g_loss": gl["total"].item(), f"it{it}_recon": gl["recon"],
+                    f"it{it}_kl": gl["kl"], f"it{it}_adv": gl["adv"], f"it{it}_recon_img": recon.detach().clone().float()})
+    return out, model.state_dict()
+
+
+def g_beta_step():
+    images = synthetic_images(2, 256, seed=46)
+    eps = [synthetic_eps((2, 128), 60 + it) for it in range(2)]
+    out, sd = _beta_step_run(torch.float32, 2, images, eps)
+    out64, _ = _beta_step_run(torch.float64, 2, images, eps)
+    out = _step_digest(out, out64, sd)
+    save("beta_step_256", images_seed=46, eps0=eps[0], eps1=eps[1], **out)
+    print({k: v for k, v in out.items() if k.startswith("noise:")})
+
+
+def _nearest_decoder(dec):
+    """D2: HierarchicalDecoder sub-blocks chained with nearest x2 upsampling (decoder.upsample.* unused)."""
+    def forward(z_list):
+        x = None
+        for j, z in enumerate(reversed(z_list)):
+            x = dec.decoders[j](z if j == 0 else torch.cat([z, F.interpolate(x, scale_factor=2, mode="nearest")], dim=1))
+        return dec.output_conv(x)
+    return forward
+
+
+def _hier_step_run(dtype, iters, images, eps):
+    """hierarchical_vae_gan/main.py:75-111 around the reference model with D2 (decoder) and D1 (target)."""
+    m = load_ref("hierarchical_vae_gan", "model")
+    cfg = load_ref("hierarchical_vae_gan", "config").Config()
+    model = filled(m.HierarchicalVAEGAN(cfg)).to(dtype).train()
+    model.decoder.forward = _nearest_decoder(model.decoder)
+    opt_g, opt_d = _adam_pair(model, cfg)
+    images = images.to(dtype)
+    target = F.avg_pool2d(images, 2)
+    out = {}
+    for it in range(iters):
+        opt_d.zero_grad()
+        with _InjectedNoise(eps[it][0]):
+            recon, _, mu_l, lv_l = model(images)
+        d_real = model.discriminator(images)
+        d_fake = model.discriminator(recon.detach())
+        dl = model.loss_function(target, recon, mu_l, lv_l, d_real, d_fake, train_generator=False)
+        dl["total"].backward()
+        opt_d.step()
+        opt_g.zero_grad()
+        with _InjectedNoise(eps[it][1]):
+            recon, _, mu_l, lv_l = model(images)
+        d_fake = model.discriminator(recon)
+        gl = model.loss_function(target, recon, mu_l, lv_l, d_real, d_fake, train_generator=True)
+        gl["total"].backward()
+        opt_g.step()
+        out.update({f"it{it}_d_loss": dl["total"].item(), f"it{it}_d_kl": dl["kl"], f"it{it}_g_loss": gl["total"].item(),
+                    f"it{it}_recon": gl["recon"], f"it{it}_kl": gl["kl"], f"it{it}_adv": gl["adv"],
+                    f"it{it}_recon_img": recon.detach().clone().float()})
+    return out, model.state_dict()
+
+
+def g_hier_step():
+    images = synthetic_images(2, 128, seed=47)
+    out, sd = _hier_step_run(torch.float32, 2, images, hier_step_eps(2, 128))
+    out64, _ = _hier_step_run(torch.float64, 2, images, hier_step_eps(2, 128))
+    out = _step_digest(out, out64, sd)
+    save("hier_step_128", images=images, **out)
+    print({k: v for k, v in out.items() if k.startswith("noise:")})
+
+
 GROUPS = {"vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
           "vq_step": g_vq_step, "losses": g_losses, "beta_modules": g_beta_modules,
-          "hier_modules": g_hier_modules}
+          "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -87,3 +87,29 @@ def test_loss_function_raises_like_reference(vg):
     out = m.loss_function(orig, recon, mu, mu, d, d, train_generator=True)
     want = torch.nn.functional.mse_loss(recon.cpu(), torch.nn.functional.avg_pool2d(orig.cpu(), 2))
     assert abs(float(out["recon"]) - float(want)) <= 1e-5 * float(want)
+
+
+def test_beta_full_step_matches_reference(vg):
+    """Two iterations of beta_vae_gans/main.py:75-108 (Adam x2, 172 M parameters, 2x3x256x256) against the golden
+    made by running the REFERENCE modules + loss_function with shim D1 (target = avg_pool2d(original, 2))."""
+    from conftest import check_step, check_state
+    from vae_gan_amd.beta_vae_gans.config import Config
+    from vae_gan_amd.beta_vae_gans.model import BetaVAEGAN
+    from vae_gan_amd.testing import fill_state_dict, synthetic_images
+    from vae_gan_amd.train import build_optimizers, beta_train_step
+    g = load_golden("beta_step_256")
+    cfg = Config()
+    cfg.recon_target_policy = "area"
+    model = BetaVAEGAN(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict()))
+    model.cuda().train()
+    opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+    images = synthetic_images(2, 256, seed=int(g["images_seed"])).cuda()
+    for it in range(2):
+        dl, gl, recon = beta_train_step(model, images, opt_g, opt_d, eps=as_t(g[f"eps{it}"]).cuda(),
+                                        elide_d_wgrad=(it == 1), return_recon=True)
+        torch.cuda.synchronize()
+        r = {"d_loss": float(dl["total"].detach()), "g_loss": float(gl["total"].detach()), "recon": float(gl["recon"]),
+             "kl": float(gl["kl"]), "adv": float(gl["adv"]), "recon_img": recon.detach().cpu()}
+        check_step(g, it, r, ("d_loss", "g_loss", "recon", "kl", "adv"))
+    check_state(g, {k: v.detach().cpu() for k, v in model.state_dict().items()}, max(float(g["noise:it1_recon_img"]), 1e-4))

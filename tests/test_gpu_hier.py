@@ -101,3 +101,33 @@ def test_composed_decoder_raises_like_reference_and_nearest_matches_oracle(vg):
     ref = O.hier_decoder_nearest({"decoder." + k: v.double() if v.dtype.is_floating_point else v.clone() for k, v in sd.items()},
                                  [z.double() for z in zs])
     close_l2(y, ref, rtol=1e-4, what="nearest composition")
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_hier_full_step_matches_reference(vg, share):
+    """Two iterations of hierarchical_vae_gan/main.py:75-111 against the golden made by running the REFERENCE
+    modules + loss_function with shims D2 (nearest composition) + D1 (area target); both the shared-encoder
+    schedule (default) and the literal two-forward schedule."""
+    from conftest import check_step, check_state
+    from vae_gan_amd.hierarchical_vae_gan.config import Config
+    from vae_gan_amd.hierarchical_vae_gan.model import HierarchicalVAEGAN
+    from vae_gan_amd.testing import fill_state_dict, hier_step_eps
+    from vae_gan_amd.train import build_optimizers, hier_train_step
+    g = load_golden("hier_step_128")
+    cfg = Config()
+    cfg.recon_target_policy, cfg.hier_decoder_policy = "area", "nearest"
+    model = HierarchicalVAEGAN(cfg)
+    model.load_state_dict(fill_state_dict(model.state_dict()))
+    model.cuda().train()
+    opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+    images = as_t(g["images"]).cuda()
+    eps = hier_step_eps(2, 128)
+    for it in range(2):
+        pair = [[e.cuda() for e in fwd] for fwd in eps[it]]
+        dl, gl, recon = hier_train_step(model, images, opt_g, opt_d, eps_lists=pair, elide_d_wgrad=(it == 1),
+                                        share_encoder=share, return_recon=True)
+        torch.cuda.synchronize()
+        r = {"d_loss": float(dl["total"].detach()), "d_kl": float(dl["kl"]), "g_loss": float(gl["total"].detach()),
+             "recon": float(gl["recon"]), "kl": float(gl["kl"]), "adv": float(gl["adv"]), "recon_img": recon.detach().cpu()}
+        check_step(g, it, r, ("d_loss", "d_kl", "g_loss", "recon", "kl", "adv"))
+    check_state(g, {k: v.detach().cpu() for k, v in model.state_dict().items()}, max(float(g["noise:it1_recon_img"]), 1e-4))

@@ -65,3 +65,32 @@ def test_vq_step_bf16_close_to_reference():
         ref = float(g[f"it0_{k}"])
         assert abs(float(v.detach()) - ref) <= 2e-2 * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_shared_encoder_equals_literal_schedule():
+    """The default step runs the encoder once per iteration and books both BatchNorm buffer updates
+    (train.vq_train_step); it must land where the literal two-forward schedule of vq_vae_gan/main.py:78,99 lands.
+    Compared after ONE iteration: from the second on, Adam's lr*sign(g) on rounding-noise gradients makes even
+    the reference's own fp32 run irreproducible below 2e-2 (noise:it1_d_loss in the golden)."""
+    from vae_gan_amd.train import vq_train_step
+    from vae_gan_amd import ops
+    g = load_golden("vq_step_64")
+    images = as_t(g["images"]).cuda()
+    runs = []
+    for share in (True, False):
+        model, opt_g, opt_d = _setup(torch.float32)
+        dl, gl, idx2 = vq_train_step(model, images, opt_g, opt_d, share_encoder=share)
+        out = (float(dl["total"].detach()), float(gl["total"].detach()), float(gl["vq"]), float(gl["recon"]), idx2.cpu())
+        runs.append((out, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    (a, sda), (b, sdb) = runs
+    for x, y in zip(a[:4], b[:4]):
+        assert abs(x - y) <= 1e-5 * abs(y), (a[:4], b[:4])
+    assert torch.equal(a[4], b[4])
+    for k in sda:
+        if sda[k].dtype == torch.int64:
+            assert int(sda[k]) == int(sdb[k]), k
+        elif "running_" in k or k.startswith("vector_quantizer"):
+            close_l2(sda[k], sdb[k], rtol=1e-5, what=k)
+        else:
+            close_l2(sda[k], sdb[k], rtol=2e-3, what=k)
+    ops.set_compute_dtype(torch.bfloat16)

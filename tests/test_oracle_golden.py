@@ -5,9 +5,9 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, as_t, close_l2, check_digests as _check_digests
+from conftest import load_golden, as_t, close_l2, check_step, check_state, check_digests as _check_digests
 from oracle import vaegan_oracle as O
-from vae_gan_amd.testing import fill_state_dict, cotangent, digest
+from vae_gan_amd.testing import fill_state_dict, cotangent, digest, hier_step_eps
 
 RTOL = 1e-4
 
@@ -216,6 +216,33 @@ def test_hier_output_conv():
     close_l2(y, g["y0"], g["noise:y0"], what="y")
     close_l2(x.grad, g["dx"], g["noise:dx"], what="dx")
     check_digests(g, sd, lambda k: k[len("output_conv."):])
+
+
+def test_hier_full_step():
+    """hierarchical_vae_gan/main.py:75-111 with the documented shims D2 + D1 (make_golden.g_hier_step: the
+    reference modules and loss_function do the arithmetic)."""
+    g = load_golden("hier_step_128")
+    sd = fill_state_dict(O.hier_template())
+    images = as_t(g["images"])
+    eps = hier_step_eps(2, 128)
+    opt = {"g": {}, "d": {}}
+    for it in range(2):
+        r = O.hier_train_step(sd, images, eps[it], O.HIER_DEFAULT_CFG, opt)
+        check_step(g, it, r, ("d_loss", "d_kl", "g_loss", "recon", "kl", "adv"))
+    check_state(g, sd, max(float(g["noise:it1_recon_img"]), 1e-4))
+
+
+def test_beta_full_step():
+    """beta_vae_gans/main.py:75-108 with shim D1; 172 M parameters, two iterations at 2x3x256x256."""
+    from vae_gan_amd.testing import synthetic_images
+    g = load_golden("beta_step_256")
+    sd = fill_state_dict(O.beta_template())
+    images = synthetic_images(2, 256, seed=int(g["images_seed"]))
+    opt = {"g": {}, "d": {}}
+    for it in range(2):
+        r = O.beta_train_step(sd, images, as_t(g[f"eps{it}"]), O.BETA_DEFAULT_CFG, opt)
+        check_step(g, it, r, ("d_loss", "g_loss", "recon", "kl", "adv"))
+    check_state(g, sd, max(float(g["noise:it1_recon_img"]), 1e-4))
 
 
 def test_template_sizes():

@@ -7,9 +7,9 @@
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int c, int cpad, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, int64_t* num_batches,
-                                   float* mean, float* invstd, float* scale, float* shift) {
+                                   int updates, float* mean, float* invstd, float* scale, float* shift) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch == 0 && num_batches != nullptr) *num_batches += 1;
+  if (ch == 0 && num_batches != nullptr) *num_batches += updates;
   if (ch >= c) return;
   double s1 = 0.0, s2 = 0.0;
   for (int r = 0; r < VG_STATS_REPLICAS; ++r) {
@@ -28,18 +28,24 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int c, int 
   shift[ch] = b - (float)m * sc;
   if (running_mean != nullptr) {
     double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
-    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    float rm = running_mean[ch], rv = running_var[ch];
+    for (int u = 0; u < updates; ++u) {
+      rm = (1.f - momentum) * rm + momentum * (float)m;
+      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    }
+    running_mean[ch] = rm;
+    running_var[ch] = rv;
   }
 }
 
 extern "C" int vg_bn_finalize(const double* stats, int c, int cpad, int64_t count, const float* gamma, const float* beta,
                               float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches,
-                              float* mean, float* invstd, float* scale, float* shift, void* stream) {
-  VG_REQUIRE(stats && mean && invstd && scale && shift && c > 0 && cpad >= c && count > 0, "bn_finalize: bad arguments");
+                              int updates, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  VG_REQUIRE(stats && mean && invstd && scale && shift && c > 0 && cpad >= c && count > 0 && updates >= 0,
+             "bn_finalize: bad arguments");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, c, cpad,
-                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, mean, invstd,
-                     scale, shift);
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, updates, mean,
+                     invstd, scale, shift);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

@@ -52,7 +52,7 @@ SIGNATURES = {
     "vg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_avgpool2_nchw": (_I, [_P, _P, _L, _I, _I, _P]),
-    "vg_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vg_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "vg_channel_stats": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),

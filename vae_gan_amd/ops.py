@@ -384,6 +384,27 @@ def channel_stats(x: torch.Tensor, c: int) -> torch.Tensor:
     return stats
 
 
+BN_UPDATES = [1]    # running-statistics updates one training-mode BatchNorm forward stands for (see bn_updates)
+
+
+class bn_updates:
+    """Inside this context one BatchNorm forward applies its running-stat update ``n`` times.  The VQ and
+    hierarchical iterations run the encoder twice on the same images with the same weights
+    (vq_vae_gan/main.py:78 and :99; only the discriminator changed in between): train-mode BatchNorm makes the
+    two passes bit-identical, so the step executes one and books the buffer updates of both."""
+
+    def __init__(self, n: int):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev, BN_UPDATES[0] = BN_UPDATES[0], self.n
+        return self
+
+    def __exit__(self, *exc):
+        BN_UPDATES[0] = self.prev
+        return False
+
+
 class BNActFn(torch.autograd.Function):
     """y = act(batchnorm_train(x) (+ res)); statistics come from the producing conv's epilogue."""
 
@@ -396,7 +417,7 @@ class BNActFn(torch.autograd.Function):
         cpad = stats.numel() // (L.STATS_REPLICAS * 2)
         vec = torch.empty(4, c, dtype=torch.float32, device=x.device)   # mean, invstd, scale, shift
         L.check(lib.vg_bn_finalize(stats.data_ptr(), c, cpad, rows, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
-                                   L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), vec[0].data_ptr(),
+                                   L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), BN_UPDATES[0], vec[0].data_ptr(),
                                    vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), L.stream()), "bn_finalize")
         y = torch.empty_like(x)
         if res is not None:

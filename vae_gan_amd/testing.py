@@ -81,6 +81,14 @@ def synthetic_eps(shape, seed: int) -> torch.Tensor:
     return torch.randn(*shape, generator=g)
 
 
+def hier_step_eps(batch: int, size: int, iters: int = 2):
+    """Injected N(0,1) draws of a hierarchical step: per iteration two forwards x three levels
+    (level order 0,1,2, hierarchical_vae_gan/model.py:368)."""
+    shapes = [(batch, 32, size // 2, size // 2), (batch, 64, size // 4, size // 4), (batch, 128, size // 8, size // 8)]
+    return [[[synthetic_eps(s, 700 + 100 * it + 10 * f + lv) for lv, s in enumerate(shapes)] for f in range(2)]
+            for it in range(iters)]
+
+
 def cotangent(name: str, shape) -> torch.Tensor:
     """Deterministic N(0,1) tensor keyed by a name (projection vector for gradient checks)."""
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)

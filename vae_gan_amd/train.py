@@ -65,22 +65,41 @@ def frozen(module):
 
 
 def vq_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[DataParallel] = None,
-                  elide_d_wgrad: bool = True):
-    """vq_vae_gan/main.py:75-111.  Returns (d_loss_dict, g_loss_dict, indices) with device scalars."""
+                  elide_d_wgrad: bool = True, share_encoder: bool = True):
+    """vq_vae_gan/main.py:75-111.  Returns (d_loss_dict, g_loss_dict, indices) with device scalars.
+
+    The reference runs the generator twice per iteration (:78 and :99).  Between the two passes only the
+    discriminator changes, so the two encoder passes are bit-identical (same images, same weights, train-mode
+    BatchNorm): with ``share_encoder`` the encoder runs once, taped, in the D phase, its BatchNorm buffers book
+    both updates (``ops.bn_updates(2)``), and the G phase starts from that ``z``.  The quantiser (EMA moved the
+    codebook in between) and the decoder run twice like the reference.  ``share_encoder=False`` is the literal
+    schedule."""
     # ---- discriminator step
     opt_d.zero_grad()
+    z = None
     with ops.step_scope(images.device):
-        with torch.no_grad():      # the D loss only sees recon.detach(): no tape for the generator pass
-            recon, _, _, vq_loss, _ = model(images)
+        if share_encoder:
+            with ops.bn_updates(2):
+                z = model.encoder(images)                       # taped: its backward runs in the G phase
+            with torch.no_grad():  # the D loss only sees recon.detach(): no tape for quantiser + decoder
+                z_q, vq_loss, _ = model.vector_quantizer(z.detach(), training=True)
+                recon = model.decoder(z_q)
+        else:
+            with torch.no_grad():
+                recon, _, _, vq_loss, _ = model(images)
         disc_real = model.discriminator(images)
         disc_fake = model.discriminator(recon)
         d_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=False)
         d_loss['total'].backward()
     opt_d.step(dp.reduce(opt_d) if dp else 1.0)
-    # ---- generator step (second full forward: EMA + BatchNorm statistics update again)
+    # ---- generator step (second forward: EMA + BatchNorm statistics update again)
     opt_g.zero_grad()
     with ops.step_scope(images.device):
-        recon, _, _, vq_loss, indices = model(images)
+        if share_encoder:
+            z_q, vq_loss, indices = model.vector_quantizer(z, training=True)
+            recon = model.decoder(z_q)
+        else:
+            recon, _, _, vq_loss, indices = model(images)
         with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
             disc_fake = model.discriminator(recon)
             g_loss = model.loss_function(images, recon, vq_loss, disc_real, disc_fake, train_generator=True)
@@ -90,7 +109,7 @@ def vq_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[
 
 
 def beta_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[DataParallel] = None, eps=None,
-                    elide_d_wgrad: bool = True):
+                    elide_d_wgrad: bool = True, return_recon: bool = False):
     """beta_vae_gans/main.py:75-108: ONE generator forward per iteration; the G step reuses recon/mu/logvar and
     only re-runs D(recon).  With the reference's shapes loss_function raises (128 vs 256) unless the model was
     built with recon_target_policy='area' (shim D1)."""
@@ -108,29 +127,43 @@ def beta_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optiona
             g_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=True)
             g_loss['total'].backward()
     opt_g.step(dp.reduce(opt_g) if dp else 1.0)
-    return d_loss, g_loss
+    return (d_loss, g_loss, recon) if return_recon else (d_loss, g_loss)
 
 
 def hier_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[DataParallel] = None, eps_lists=(None, None),
-                    elide_d_wgrad: bool = True):
+                    elide_d_wgrad: bool = True, share_encoder: bool = True, return_recon: bool = False):
     """hierarchical_vae_gan/main.py:75-111: two generator forwards per iteration (fresh N(0,1) draws for each of the
     three levels in both).  Needs hier_decoder_policy='nearest' + recon_target_policy='area' (shims D2 + D1): with the
-    reference's own composition the decoder raises."""
+    reference's own composition the decoder raises.  ``share_encoder``: as in ``vq_train_step`` (the two encoder
+    passes are bit-identical; the reparameterisation draws and the decoder are not and run twice)."""
     opt_d.zero_grad()
+    mu_list = logvar_list = None
     with ops.step_scope(images.device):
-        with torch.no_grad():      # the D loss only sees recon.detach(): no tape for the generator pass
-            recon, _, mu_list, logvar_list = model(images, eps_lists[0])
+        if share_encoder:
+            with ops.bn_updates(2):
+                mu_list, logvar_list = model.encoder(images)    # taped: its backward runs in the G phase
+            with torch.no_grad():
+                mu_d, lv_d = [m.detach() for m in mu_list], [v.detach() for v in logvar_list]
+                eps = eps_lists[0] or [None] * len(mu_d)
+                recon = model.decode([model.reparameterize(m, v, e) for m, v, e in zip(mu_d, lv_d, eps)])
+        else:
+            with torch.no_grad():  # the D loss only sees recon.detach(): no tape for the generator pass
+                recon, _, mu_d, lv_d = model(images, eps_lists[0])
         disc_real = model.discriminator(images)
         disc_fake = model.discriminator(recon)
-        d_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=False)
+        d_loss = model.loss_function(images, recon, mu_d, lv_d, disc_real, disc_fake, train_generator=False)
         d_loss['total'].backward()
     opt_d.step(dp.reduce(opt_d) if dp else 1.0)
     opt_g.zero_grad()
     with ops.step_scope(images.device):
-        recon, _, mu_list, logvar_list = model(images, eps_lists[1])
+        if share_encoder:
+            eps = eps_lists[1] or [None] * len(mu_list)
+            recon = model.decode([model.reparameterize(m, v, e) for m, v, e in zip(mu_list, logvar_list, eps)])
+        else:
+            recon, _, mu_list, logvar_list = model(images, eps_lists[1])
         with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
             disc_fake = model.discriminator(recon)
             g_loss = model.loss_function(images, recon, mu_list, logvar_list, disc_real, disc_fake, train_generator=True)
             g_loss['total'].backward()
     opt_g.step(dp.reduce(opt_g) if dp else 1.0)
-    return d_loss, g_loss
+    return (d_loss, g_loss, recon) if return_recon else (d_loss, g_loss)
