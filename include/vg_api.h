@@ -126,11 +126,13 @@ int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float
  * dgamma = sum_dzxhat, dbeta = sum_dz (f32 [c]). */
 /* NOTE: `sums` must be followed by 3*cpad f32 of scratch (coefficients), i.e. allocate
  * VG_STATS_REPLICAS*2*cpad f64 + 3*cpad f32. */
-/* y may be NULL under the same conditions as in vg_bn_bwd_reduce.  accumulate != 0: dgamma, dbeta +=. */
+/* y may be NULL under the same conditions as in vg_bn_bwd_reduce.  accumulate != 0: dgamma, dbeta +=.
+ * dxsum (optional, f32 [c]) += per-channel sum of the stored dx: the bias gradient of the conv that produced x
+ * (nn.Conv2d bias backward, e.g. vq_vae_gan/model.py:17-18), taken here instead of by one more pass over dx. */
 int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                     const float* scale, const float* shift, const float* gamma, const double* sums, void* dx,
-                    void* dres, float* dgamma, float* dbeta, int accumulate, int64_t rows, int cs, int c, int cpad,
-                    int act, int dtype, void* stream);
+                    void* dres, float* dgamma, float* dbeta, int accumulate, float* dxsum, int64_t rows, int cs, int c,
+                    int cpad, int act, int dtype, void* stream);
 /* Plain elementwise activation backward (no BN): dx = dout * act'(y). */
 int vg_act_bwd(const void* dout, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
 /* a += b (elementwise, `dtype`): gradient fan-in of the residual skip. */

@@ -248,12 +248,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef,
-                                                           T* __restrict__ dx, T* __restrict__ dres, int64_t rows,
+                                                           T* __restrict__ dx, T* __restrict__ dres,
+                                                           float* __restrict__ dxsum, int64_t rows,
                                                            int ppr, int c, int cpad, int act) {
   constexpr int PIECE = Elt<T>::PIECE;
+  __shared__ float red[256 * PIECE];
   const int rpb = 256 / ppr;
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
-  if (rr >= rpb) return;
+  if (rr >= rpb && dxsum == nullptr) return;
+  float acc[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) acc[e] = 0.f;
   // d = a*(dz - m1 - xh*m2), xh = (x-mu)*is  ==  a*dz - (a*m1 - a*m2*is*mu) - (a*m2*is)*x
   float ca[PIECE], cb[PIECE], cx[PIECE], sc[PIECE], sh[PIECE];
 #pragma unroll
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
   }
   const size_t cs = (size_t)ppr * PIECE;
-  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; rr < rpb && r < rows; r += (int64_t)gridDim.x * rpb) {
     const size_t off = (size_t)r * cs + pc * PIECE;
     Piece<T> g, o, v, rx, rd;
     g.v = *(const decltype(g.v)*)(dout + off);
@@ -281,17 +286,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       if (act == VG_ACT_LRELU && !(yv > 0.f)) dz *= VG_LRELU_SLOPE;
       if (pc * PIECE + e >= c) dz = 0.f;
       rx.set(e, ca[e] * dz - cb[e] - cx[e] * v.get(e));
+      acc[e] += rx.get(e);            // the value as stored (the producing conv's bias gradient sums these)
       if (HAS_DRES) rd.set(e, dz);
     }
     *(decltype(rx.v)*)(dx + off) = rx.v;
     if (HAS_DRES) *(decltype(rd.v)*)(dres + off) = rd.v;
   }
+  if (dxsum != nullptr) {     // block-uniform: per-channel sum of dx over this block's rows, one f32 atomic per channel
+    const int width = ppr * PIECE;
+    if (rr < rpb) {
+#pragma unroll
+      for (int e = 0; e < PIECE; ++e) red[rr * width + pc * PIECE + e] = acc[e];
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+      float t = 0.f;
+      for (int r2 = 0; r2 < rpb; ++r2) t += red[r2 * width + ch];
+      unsafeAtomicAdd(&dxsum[ch], t);
+    }
+  }
 }
 
 extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                                const float* scale, const float* shift, const float* gamma, const double* sums, void* dx,
-                               void* dres, float* dgamma, float* dbeta, int accumulate, int64_t rows, int cs, int c,
-                               int cpad, int act, int dtype, void* stream) {
+                               void* dres, float* dgamma, float* dbeta, int accumulate, float* dxsum, int64_t rows, int cs,
+                               int c, int cpad, int act, int dtype, void* stream) {
   VG_REQUIRE(dout && x && mean && invstd && sums && dx && rows > 0 && cs >= c && cpad >= c, "bn_bwd_apply: bad arguments");
   VG_REQUIRE(y || (scale && shift), "bn_bwd_apply: need y, or scale and shift to recompute the activation mask from x");
   VG_REQUIRE(y || act == VG_ACT_LRELU || act == VG_ACT_NONE, "bn_bwd_apply: y is required for this activation");
@@ -309,7 +328,7 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   dim3 g(row_blocks(rows, 256 / ppr, 8)), b(256);
 #define VG_BN_APPLY(T, DR, XM)                                                                                      \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DR, XM>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
-                     scale, shift, coef, (T*)dx, (T*)dres, np, ppr, c, cpad, act)
+                     scale, shift, coef, (T*)dx, (T*)dres, dxsum, np, ppr, c, cpad, act)
   if (dtype == VG_BF16) {
     if (dres) { if (xmask) VG_BN_APPLY(bf16_t, true, true); else VG_BN_APPLY(bf16_t, true, false); }
     else { if (xmask) VG_BN_APPLY(bf16_t, false, true); else VG_BN_APPLY(bf16_t, false, false); }

@@ -1009,7 +1009,14 @@ template <typename T, int R, int S> static int dispatch_igemm3_rs(const IgemmPar
     if constexpr (Igemm3Cfg<T, 4, 2, 4, 2, R, S>::FITS) return launch_igemm3<T, 4, 2, 4, 2, R, S>(p, st, handled);   // 16x32 px x 128 ch
     else return launch_igemm3<T, 2, 2, 4, 2, R, S>(p, st, handled);               // 8x32 px x 128 ch (three halo buffers fit)
   }
-  if (p.Npad == 64) return launch_igemm3<T, 2, 2, 8, 1, R, S>(p, st, handled);        // 16x32 px x 64 ch
+  if (p.Npad == 64) {
+    // 3x3: 8x32 px x 64 ch (75 KB of LDS, 94 VGPRs: two blocks per CU overlap each other's prologue and epilogue)
+    if constexpr (R == 3) return launch_igemm3<T, 1, 2, 8, 1, R, S>(p, st, handled);
+    else return launch_igemm3<T, 2, 2, 8, 1, R, S>(p, st, handled);                   // 16x32 px x 64 ch
+  }
+  if constexpr (R == 3) {
+    if (p.Npad == 32) return launch_igemm3<T, 1, 1, 8, 1, R, S>(p, st, handled);      // thin outputs (64->3, d/dx of 3->64)
+  }
   return VG_OK;
 }
 template <typename T> static int dispatch_igemm3(const IgemmParams& p, hipStream_t st, bool* handled) {

@@ -36,8 +36,9 @@ class Conv2d(nn.Module):
         bound = 1 / math.sqrt(fan_in)
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def run(self, x, act=L.ACT_NONE, want_stats=False):
-        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.stride, self.padding, act, want_stats, self._packs)
+    def run(self, x, act=L.ACT_NONE, want_stats=False, link=None, reslink=None):
+        return ops.Conv2dFn.apply(x, self.weight, self.bias, self.stride, self.padding, act, want_stats, self._packs, link,
+                                  reslink)
 
     def forward(self, x):
         return self.run(x)[0]
@@ -57,8 +58,9 @@ class ConvTranspose2d(nn.Module):
         bound = 1 / math.sqrt(out_channels * kernel_size ** 2)   # torch: fan_in computed on dim 1
         nn.init.uniform_(self.bias, -bound, bound)
 
-    def run(self, x, act=L.ACT_NONE, want_stats=False):
-        return ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.stride, self.padding, act, want_stats, self._packs)
+    def run(self, x, act=L.ACT_NONE, want_stats=False, link=None):
+        return ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.stride, self.padding, act, want_stats, self._packs,
+                                           link)
 
     def forward(self, x):
         return self.run(x)[0]
@@ -76,15 +78,16 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def run(self, x, stats, act=L.ACT_NONE, res=None):
-        """x: raw NHWC conv output; stats: from the conv epilogue (or None → computed here)."""
+    def run(self, x, stats, act=L.ACT_NONE, res=None, link=None, reslink=None):
+        """x: raw NHWC conv output; stats: from the conv epilogue (or None → computed here);
+        link: ops.BiasLink of the conv that produced x (its bias gradient is taken by this layer's backward)."""
         c = self.num_features
         if not self.training:
             return ops.bn_eval_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, act, c, res)
         if stats is None:
             stats = ops.channel_stats(x.contiguous(), c)
         return ops.BNActFn.apply(x, stats, self.weight, self.bias, res, self.running_mean, self.running_var,
-                                 self.num_batches_tracked, self.eps, self.momentum, act, c)
+                                 self.num_batches_tracked, self.eps, self.momentum, act, c, link, reslink)
 
     def forward(self, x):
         return self.run(x, None)
@@ -121,10 +124,13 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         train = self.training
-        h, st = self.conv1.run(x, want_stats=train)
-        h = self.bn1.run(h, st, L.ACT_LRELU)
-        h, st = self.conv2.run(h, want_stats=train)
-        return self.bn2.run(h, st, L.ACT_LRELU, res=x)
+        l1 = ops.BiasLink(self.conv1.bias) if train else None
+        l2 = ops.BiasLink(self.conv2.bias) if train else None
+        rl = ops.ResLink() if (train and x.requires_grad) else None
+        h, st = self.conv1.run(x, want_stats=train, link=l1, reslink=rl)
+        h = self.bn1.run(h, st, L.ACT_LRELU, link=l1)
+        h, st = self.conv2.run(h, want_stats=train, link=l2)
+        return self.bn2.run(h, st, L.ACT_LRELU, res=x, link=l2, reslink=rl)
 
 
 class FusedSequential(nn.Sequential):
@@ -150,8 +156,9 @@ class FusedSequential(nn.Sequential):
                 if bn is None:
                     x = m.run(x, act=act)[0]
                 else:
-                    raw, st = m.run(x, want_stats=bn.training)
-                    x = bn.run(raw, st, act)
+                    link = ops.BiasLink(m.bias) if bn.training else None
+                    raw, st = m.run(x, want_stats=bn.training, link=link)
+                    x = bn.run(raw, st, act, link=link)
                 i = j
             elif isinstance(m, BatchNorm2d):
                 j = i + 1

@@ -273,12 +273,40 @@ def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape, param=No
     return None if slot is not None else dw
 
 
+class BiasLink:
+    """Ties a conv to the BatchNorm that consumes its raw output.  The conv's bias gradient is the per-channel sum
+    of the BatchNorm input gradient; ``vg_bn_bwd_apply`` takes that sum while it writes dx, straight into the bias
+    ``.grad`` (inside ``step_scope``), and marks the link so that the conv's backward skips its own pass over dx."""
+    __slots__ = ("bias", "done")
+
+    def __init__(self, bias):
+        self.bias, self.done = bias, False
+
+
+class ResLink:
+    """Ties the first conv of a ResidualBlock to the block's last BatchNorm: both send a gradient to the block
+    input (conv path and identity skip).  The BatchNorm backward parks its skip gradient here instead of returning
+    it, and the conv's input-gradient kernel accumulates onto it in its epilogue: no separate add pass."""
+    __slots__ = ("dres",)
+
+    def __init__(self):
+        self.dres = None
+
+
+def _bias_done(link) -> bool:
+    if link is None or not link.done:
+        return False
+    link.done = False
+    return True
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = act(conv2d(x, W) + b) on NHWC tensors; optionally emits BatchNorm statistics."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None, reslink=None):
         _require_cuda(x, "conv2d")
+        ctx.link, ctx.reslink = link, reslink
         x = x.contiguous()
         n, h, w, xcs = x.shape
         co, ci, k, _ = weight.shape
@@ -310,23 +338,30 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             wpt = ctx.packs.get(weight, d, 1, x.dtype)
-            dx = torch.empty_like(x)
+            parked = ctx.reslink.dres if ctx.reslink is not None else None
+            if parked is not None:          # skip-path gradient of the enclosing ResidualBlock: accumulate onto it
+                ctx.reslink.dres = None
+                dx = parked
+            else:
+                dx = torch.empty_like(x)
             L.check(_timed(None, _conv_flops(d),
                            lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
-                                                     L.ACT_NONE, 0, L.stream()), _shape_tag("dgrad", d)), "conv_dgrad")
+                                                     L.ACT_NONE, int(parked is not None), L.stream()),
+                           _shape_tag("dgrad", d)), "conv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, x, gy, weight.shape, ctx.wparam)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not _bias_done(ctx.link):
             db = _channel_sum(gy, d.co, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
     """y = act(conv_transpose2d(x, W) + b): the dgrad kernel of the conv object W[O=in][I=out]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None):
         _require_cuda(x, "conv_transpose2d")
+        ctx.link = link
         x = x.contiguous()
         n, h, w, xcs = x.shape
         cin_t, cout_t, k, _ = weight.shape
@@ -367,9 +402,9 @@ class ConvTranspose2dFn(torch.autograd.Function):
                                                    L.ACT_NONE, 0, L.stream()), _shape_tag("convT_dgrad", d)), "convT_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, gy, x, weight.shape, ctx.wparam)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not _bias_done(ctx.link):
             db = _channel_sum(gy, d.ci, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -409,7 +444,7 @@ class BNActFn(torch.autograd.Function):
     """y = act(batchnorm_train(x) (+ res)); statistics come from the producing conv's epilogue."""
 
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, res, running_mean, running_var, nbt, eps, momentum, act, c):
+    def forward(ctx, x, stats, gamma, beta, res, running_mean, running_var, nbt, eps, momentum, act, c, link=None, reslink=None):
         lib = L.load()
         x = x.contiguous()
         cs = x.shape[-1]
@@ -425,7 +460,7 @@ class BNActFn(torch.autograd.Function):
         L.check(lib.vg_bn_act_fwd(x.data_ptr(), L.ptr(res), y.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), rows, cs, c,
                                   act, L.vg_dtype(x.dtype), L.stream()), "bn_act_fwd")
         ctx.c, ctx.cpad, ctx.act, ctx.has_res = c, cpad, act, res is not None
-        ctx.gparam, ctx.bparam = gamma, beta
+        ctx.gparam, ctx.bparam, ctx.link, ctx.reslink = gamma, beta, link, reslink
         ctx.save_for_backward(x, y, vec, gamma)
         return y
 
@@ -449,13 +484,21 @@ class BNActFn(torch.autograd.Function):
         gslot, bslot = _grad_slot(ctx.gparam), _grad_slot(ctx.bparam)
         direct = gslot is not None and bslot is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
         dgb = (gslot, bslot) if direct else torch.empty(2, c, dtype=torch.float32, device=x.device)
+        # bias gradient of the producing conv = per-channel sum of dx: taken by the same kernel (see BiasLink)
+        link = ctx.link
+        cbslot = _grad_slot(link.bias) if (link is not None and link.bias is not None and link.bias.requires_grad) else None
         L.check(lib.vg_bn_bwd_apply(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
                                     vec[2].data_ptr(), vec[3].data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(),
                                     L.ptr(dres), dgb[0].data_ptr(),
-                                    dgb[1].data_ptr(), int(direct), rows, cs, c, cpad, ctx.act, dtc, L.stream()), "bn_bwd_apply")
+                                    dgb[1].data_ptr(), int(direct), L.ptr(cbslot), rows, cs, c, cpad, ctx.act, dtc,
+                                    L.stream()), "bn_bwd_apply")
+        if cbslot is not None:
+            link.done = True
+        if dres is not None and ctx.reslink is not None and _STEP[0] and ctx.needs_input_grad[4]:
+            ctx.reslink.dres, dres = dres, None      # picked up by the block's first conv (see ResLink)
         if direct:
-            return dx, None, None, None, dres, None, None, None, None, None, None, None
-        return dx, None, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
+            return dx, None, None, None, dres, None, None, None, None, None, None, None, None, None
+        return dx, None, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None, None
 
 
 def bn_eval_act(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, act: int, c: int,
