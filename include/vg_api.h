@@ -128,11 +128,14 @@ int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float
  * VG_STATS_REPLICAS*2*cpad f64 + 3*cpad f32. */
 /* y may be NULL under the same conditions as in vg_bn_bwd_reduce.  accumulate != 0: dgamma, dbeta +=.
  * dxsum (optional, f32 [c]) += per-channel sum of the stored dx: the bias gradient of the conv that produced x
- * (nn.Conv2d bias backward, e.g. vq_vae_gan/model.py:17-18), taken here instead of by one more pass over dx. */
+ * (nn.Conv2d bias backward, e.g. vq_vae_gan/model.py:17-18), taken here instead of by one more pass over dx.
+ * count = number of rows the sums run over (0: = rows; data parallel with global-batch statistics: the rows of
+ * all ranks, `sums` having been summed over the ranks); dgamma/dbeta are the sums times dgb_scale (1, or 1/world
+ * in that mode, where every rank holds the global sums and the gradient exchange adds them up again). */
 int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                     const float* scale, const float* shift, const float* gamma, const double* sums, void* dx,
-                    void* dres, float* dgamma, float* dbeta, int accumulate, float* dxsum, int64_t rows, int cs, int c,
-                    int cpad, int act, int dtype, void* stream);
+                    void* dres, float* dgamma, float* dbeta, int accumulate, float* dxsum, int64_t rows, int64_t count,
+                    float dgb_scale, int cs, int c, int cpad, int act, int dtype, void* stream);
 /* Plain elementwise activation backward (no BN): dx = dout * act'(y). */
 int vg_act_bwd(const void* dout, const void* y, void* dx, int64_t n, int act, int dtype, void* stream);
 /* a += b (elementwise, `dtype`): gradient fan-in of the residual skip. */

@@ -54,3 +54,73 @@ def test_single_process_is_identity():
     dp = DataParallel()
     opt = types.SimpleNamespace(flat_g=torch.ones(8))
     assert dp.reduce(opt) == 1.0 and dp.world == 1
+
+
+def _worker_buckets(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_gan_amd.train import DataParallel
+    dp = DataParallel(bucket_bytes=64)             # 16-element pieces
+    # three parameter groups laid out like FlatAdam does (gradients are views into one flat buffer)
+    sizes = [40, 24, 56]
+    params = [torch.nn.Parameter(torch.full((n,), 0.5 + i)) for i, n in enumerate(sizes)]
+    offsets = [0, 40, 64]
+    flat_g = torch.zeros(sum(sizes))
+    for p, o in zip(params, offsets):
+        p.grad = flat_g[o:o + p.numel()]
+    opt = types.SimpleNamespace(params=params, offsets=offsets, numel=flat_g.numel(), flat_g=flat_g)
+    x = torch.full((8,), float(rank + 1), requires_grad=True)
+    h = x * params[0][:8].sum()                       # "encoder": group 0
+    fired = []
+    h = dp.mark(h, opt, params[1:])                   # "decoder": groups 1 and 2, exchanged from the boundary
+    orig_send = dp._send
+    dp._send = lambda o, lo, hi: (fired.append((lo, hi)), orig_send(o, lo, hi))[1]
+    y = (h * params[1][:8]).sum() + (h.sum() * params[2]).sum()
+    y.backward()
+    after_backward = list(fired)
+    scale = dp.reduce(opt)
+    # expected: the same graph evaluated for every rank's x, gradients added up
+    want = torch.zeros_like(flat_g)
+    for r in range(world):
+        ps = [torch.nn.Parameter(p.detach().clone()) for p in params]
+        xr = torch.full((8,), float(r + 1))
+        hr = xr * ps[0][:8].sum()
+        ((hr * ps[1][:8]).sum() + (hr.sum() * ps[2]).sum()).backward()
+        for p, o in zip(ps, offsets):
+            want[o:o + p.numel()] += p.grad
+    out[rank] = (after_backward == [(40, 120)] and fired == [(40, 120), (0, 40)] and dp.n_async == 1
+                 and torch.allclose(flat_g, want) and abs(scale - 1.0 / world) < 1e-12
+                 and DataParallel.span(opt, params[:2]) == (0, 64))
+    dist.destroy_process_group()
+
+
+def test_dp_bucket_boundaries_world2():
+    """A boundary fires from inside the backward pass once its group's gradients exist; reduce() sends the rest."""
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_buckets, args=(world, port, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def _worker_stats(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_gan_amd import ops
+    from vae_gan_amd.train import DataParallel
+    dp = DataParallel(bn_sync="global")
+    ok = ops.STAT_SYNC[0] is dp
+    t = torch.full((6,), float(rank + 1), dtype=torch.float64)
+    dp.sum_(t)
+    ok = ok and bool((t == sum(r + 1 for r in range(world))).all())
+    dp.close()
+    out[rank] = ok and ops.STAT_SYNC[0] is None
+    dist.destroy_process_group()
+
+
+def test_dp_global_statistics_hook_world2():
+    world = 2
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_stats, args=(world, port, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)

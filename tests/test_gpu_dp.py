@@ -1,0 +1,133 @@
+"""GPU tier: data parallel with global-batch statistics.  Two ranks share the one GPU of the test box (gloo moves the
+small exchanges through the host; RCCL needs one GPU per rank) and take ONE image each of the 2-image batch of the
+vq_step_64 golden.  With ``bn_sync='global'`` the BatchNorm statistics, the VQ-EMA statistics and the averaged
+gradients are those of the whole batch, so the two-rank run must land on the single-device reference run."""
+import os
+import socket
+
+import pytest
+import torch
+
+from conftest import load_golden, as_t
+from vae_gan_amd.testing import fill_state_dict, digest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_gan_amd import ops
+    from vae_gan_amd.train import DataParallel, build_optimizers, vq_train_step
+    from vae_gan_amd.vq_vae_gan.config import Config
+    from vae_gan_amd.vq_vae_gan.model import VQVAEGAN
+    ops.set_compute_dtype(torch.float32)
+    g = load_golden("vq_step_64")
+    cfg = Config()
+    model = VQVAEGAN(cfg)
+    sd0 = fill_state_dict(model.state_dict())
+    if rank != 0:                       # only rank 0 starts from the right weights: broadcast_model must fix the others
+        sd0 = {k: (v * 0.5 if v.dtype.is_floating_point else v) for k, v in sd0.items()}
+    model.load_state_dict(sd0)
+    model.cuda().train()
+    dp = DataParallel(bn_sync="global", bucket_bytes=8 << 20)
+    dp.broadcast_model(model)
+    opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+    images = as_t(g["images"])[rank:rank + 1].cuda()
+    res = {}
+    for it in range(2):
+        dl, gl, idx2 = vq_train_step(model, images, opt_g, opt_d, dp)
+        torch.cuda.synchronize()
+        res[it] = {"d_loss": float(dl["total"].detach()), "d_recon": float(dl["recon"]), "g_loss": float(gl["total"].detach()),
+                   "recon": float(gl["recon"]), "vq": float(gl["vq"]), "adv": float(gl["adv"]), "idx2": idx2.cpu().tolist()}
+    sd = model.state_dict()
+    res["nbt"] = {k: int(v) for k, v in sd.items() if v.dtype == torch.int64}
+    res["l2"] = {k: float(digest(k, v)[0]) for k, v in sd.items() if v.dtype != torch.int64}
+    res["n_async"] = dp.n_async
+    out[rank] = res
+    dp.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_global_statistics_match_single_device_reference():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import torch.multiprocessing as mp
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    g = load_golden("vq_step_64")
+    r0, r1 = out[0], out[1]
+    assert r0["n_async"] == 2 and r1["n_async"] == 2      # decoder slice sent from the backward boundary, both iterations
+    for it in range(2):
+        floor = 4 * float(g[f"noise:it{it}_recon_img"]) if it else 0.0
+        for k in ("d_loss", "d_recon", "g_loss", "recon", "vq", "adv"):
+            mine = 0.5 * (r0[it][k] + r1[it][k])          # every loss is a mean over the batch: average of the two halves
+            ref = float(g[f"it{it}_{k}"])
+            tol = max(1e-4, 4 * float(g[f"noise:it{it}_{k}"]), floor)
+            scale = max(abs(ref), 1e-3, abs(float(g[f"it{it}_d_loss"])) if k == "adv" else 0.0)
+            assert abs(mine - ref) <= tol * scale, (it, k, mine, ref, tol)
+        idx = torch.tensor([r0[it]["idx2"][0], r1[it]["idx2"][0]])
+        match = (idx == as_t(g[f"it{it}_idx2"])).float().mean().item()
+        assert match >= (1.0 if it == 0 else float(g["idxeq64:it1_idx2"]) - 0.02), (it, match)
+    noise = max(float(g["noise:it1_recon_img"]), 1e-4)
+    for key, ref in g.items():
+        if key.startswith("sd:") and key[3:] in r0["nbt"]:
+            assert r0["nbt"][key[3:]] == int(ref) == r1["nbt"][key[3:]], key
+        elif key.startswith("sdd:"):
+            k = key[4:]
+            assert abs(r0["l2"][k] - ref[0]) <= max(1e-4, 4 * noise) * max(ref[0], 1e-6), k
+            assert abs(r0["l2"][k] - r1["l2"][k]) <= 1e-6 * max(ref[0], 1e-6), k      # replicas stay in lock step
+
+
+def _worker_rccl(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from vae_gan_amd import ops
+    from vae_gan_amd.train import DataParallel, build_optimizers, vq_train_step
+    from vae_gan_amd.vq_vae_gan.config import Config
+    from vae_gan_amd.vq_vae_gan.model import VQVAEGAN
+    ops.set_compute_dtype(torch.float32)
+    g = load_golden("vq_step_64")
+    cfg = Config()
+    res = []
+    for use_dp in (False, True):
+        model = VQVAEGAN(cfg)
+        model.load_state_dict(fill_state_dict(model.state_dict()))
+        model.cuda().train()
+        opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+        dp = None
+        if use_dp:
+            dp = DataParallel(bucket_bytes=4 << 20)
+            dp.world = 2            # one-rank RCCL communicator, but take every multi-rank code path (sum over 1 rank = identity)
+        dl, gl, idx2 = vq_train_step(model, as_t(g["images"]).cuda(), opt_g, opt_d, dp)
+        torch.cuda.synchronize()
+        res.append((float(dl["total"].detach()), float(gl["total"].detach()), idx2.cpu(), opt_g.flat_g.clone().cpu(),
+                    dp.n_async if dp else 0))
+    (d0, g0, i0, f0, _), (d1, g1, i1, f1, n1) = res
+    out[0] = (abs(d0 - d1) <= 1e-5 * abs(d0) and abs(g0 - g1) <= 1e-5 * abs(g0) and bool(torch.equal(i0, i1))
+              and float((f0 - f1).norm() / f0.norm()) < 1e-4 and n1 == 1)
+    dist.destroy_process_group()
+
+
+def test_rccl_stream_path_one_rank():
+    """The RCCL code path (side stream, event hand-over, bucketed async all-reduce, compute stream waiting on it) on a
+    one-rank communicator: the exchange is an identity, so gradients and losses must equal the run without it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rccl, args=(1, _free_port(), out), nprocs=1, join=True)
+    assert out.get(0) is True, dict(out)

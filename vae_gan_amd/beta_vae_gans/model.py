@@ -39,6 +39,7 @@ class Encoder(nn.Module):
         fc_in = hidden_channels[-1] * self.feature_map_size ** 2
         self.fc_mu = Linear(fc_in, latent_dim)
         self.fc_logvar = Linear(fc_in, latent_dim)
+        self.grad_boundary = None     # data parallel: callable put on the flattened features (bucket boundary)
 
     def forward(self, x):
         f = ops.to_nchw(self.features(ops.to_nhwc(x)), self.last_channels)     # NCHW flatten order of the FC weights
@@ -46,6 +47,8 @@ class Encoder(nn.Module):
         if f.shape[1] != self.fc_mu.in_features:
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({f.shape[0]}x{f.shape[1]} and "
                                f"{self.fc_mu.in_features}x{self.fc_mu.out_features})")
+        if self.grad_boundary is not None:
+            f = self.grad_boundary(f)
         mu = self.fc_mu(f)
         logvar = ops.clamp(self.fc_logvar(f), -20, 20)
         return mu, logvar

@@ -228,7 +228,7 @@ extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, 
 __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int cpad, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
                                    float* __restrict__ coef /* [3][cpad]: a = gamma*invstd, m1 = sum_dz/n, m2 = sum_dzxh/n */,
-                                   float* dgamma, float* dbeta, int accumulate) {
+                                   float* dgamma, float* dbeta, int accumulate, float dgb_scale) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   double s1 = 0.0, s2 = 0.0;
@@ -239,8 +239,9 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
   coef[ch] = (gamma ? gamma[ch] : 1.f) * invstd[ch];
   coef[cpad + ch] = (float)(s1 / count);
   coef[2 * cpad + ch] = (float)(s2 / count);
-  if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + (float)s2 : (float)s2;
-  if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + (float)s1 : (float)s1;
+  const float g2 = (float)(s2 * (double)dgb_scale), g1 = (float)(s1 * (double)dgb_scale);
+  if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + g2 : g2;
+  if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + g1 : g1;
 }
 
 template <typename T, bool HAS_DRES, bool XMASK>
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                                const float* scale, const float* shift, const float* gamma, const double* sums, void* dx,
-                               void* dres, float* dgamma, float* dbeta, int accumulate, float* dxsum, int64_t rows, int cs,
-                               int c, int cpad, int act, int dtype, void* stream) {
+                               void* dres, float* dgamma, float* dbeta, int accumulate, float* dxsum, int64_t rows,
+                               int64_t count, float dgb_scale, int cs, int c, int cpad, int act, int dtype, void* stream) {
   VG_REQUIRE(dout && x && mean && invstd && sums && dx && rows > 0 && cs >= c && cpad >= c, "bn_bwd_apply: bad arguments");
   VG_REQUIRE(y || (scale && shift), "bn_bwd_apply: need y, or scale and shift to recompute the activation mask from x");
   VG_REQUIRE(y || act == VG_ACT_LRELU || act == VG_ACT_NONE, "bn_bwd_apply: y is required for this activation");
@@ -321,7 +322,7 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   hipStream_t st = (hipStream_t)stream;
   // coefficient scratch lives right behind the f64 sums (caller allocates [REPLICAS*2*cpad] f64 + 3*cpad f32)
   float* coef = (float*)(sums + (size_t)VG_STATS_REPLICAS * 2 * cpad);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)rows, gamma, invstd, coef, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)(count > 0 ? count : rows), gamma, invstd, coef, dgamma, dbeta, accumulate, dgb_scale);
   VG_LAUNCH_CHECK();
   const int ppr = cs / piece;
   const int64_t np = rows;

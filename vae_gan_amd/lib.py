@@ -56,7 +56,7 @@ SIGNATURES = {
     "vg_channel_stats": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
-    "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _F, _I, _I, _I, _I, _I, _P]),
     "vg_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "vg_add_inplace": (_I, [_P, _P, _L, _I, _P]),
     "vg_vq_assign": (_I, [_P, _P, _L, _I, _I, _P, _P]),

@@ -34,17 +34,23 @@ class KernelProfile:
     """Optional per-launch HIP-event timing of the conv kernels (bench.py's live roofline numbers).
     Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
 
-    def __init__(self, shapes: bool = False):
+    def __init__(self, shapes: bool = False, only_tags=None):
         self.records = []     # (kernel name, algorithmic flops, start event, end event)
         self.shapes = shapes  # key the summary by layer shape as well (diagnostics)
+        self.only_tags = only_tags   # set of layer-shape tags to time (None = every conv launch)
+        self.tag_kernel = {}  # layer-shape tag -> kernel variant the library dispatched
 
     def launch(self, name, flops, fn, tag=None):
+        if self.only_tags is not None and tag not in self.only_tags:
+            return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn()
         e1.record()
         if name is None:      # gather-GEMM launch: ask the library which kernel variant it dispatched
             name = L.load().vg_last_conv_kernel().decode()
+        if tag is not None:
+            self.tag_kernel[tag] = name
         if self.shapes and tag is not None:
             name += " " + tag
         self.records.append((name, flops, e0, e1))
@@ -419,6 +425,12 @@ def channel_stats(x: torch.Tensor, c: int) -> torch.Tensor:
     return stats
 
 
+# Data parallel with global-batch statistics (train.DataParallel(bn_sync='global')): an object with ``world`` and
+# ``sum_(tensor)`` (in-place sum over the ranks).  The reference is single-device, so its BatchNorm batch statistics
+# and its VQ-EMA counts run over the WHOLE batch; with this set, every rank normalises with the statistics of the
+# global batch (forward sums, backward sums and EMA statistics are summed over the ranks before they are used).
+STAT_SYNC = [None]
+
 BN_UPDATES = [1]    # running-statistics updates one training-mode BatchNorm forward stands for (see bn_updates)
 
 
@@ -451,7 +463,13 @@ class BNActFn(torch.autograd.Function):
         rows = x.numel() // cs
         cpad = stats.numel() // (L.STATS_REPLICAS * 2)
         vec = torch.empty(4, c, dtype=torch.float32, device=x.device)   # mean, invstd, scale, shift
-        L.check(lib.vg_bn_finalize(stats.data_ptr(), c, cpad, rows, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+        sync = STAT_SYNC[0]
+        count = rows
+        if sync is not None:
+            sync.sum_(stats)
+            count = rows * sync.world
+        ctx.count, ctx.sync = count, sync
+        L.check(lib.vg_bn_finalize(stats.data_ptr(), c, cpad, count, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                    L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), BN_UPDATES[0], vec[0].data_ptr(),
                                    vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), L.stream()), "bn_finalize")
         y = torch.empty_like(x)
@@ -479,6 +497,9 @@ class BNActFn(torch.autograd.Function):
         L.check(lib.vg_bn_bwd_reduce(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
                                      vec[2].data_ptr(), vec[3].data_ptr(), sums.data_ptr(), rows, cs, c, cpad, ctx.act, dtc,
                                      L.stream()), "bn_bwd_reduce")
+        sync = ctx.sync
+        if sync is not None:
+            sync.sum_(sums[:L.STATS_REPLICAS * 2 * cpad])
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         gslot, bslot = _grad_slot(ctx.gparam), _grad_slot(ctx.bparam)
@@ -490,7 +511,8 @@ class BNActFn(torch.autograd.Function):
         L.check(lib.vg_bn_bwd_apply(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
                                     vec[2].data_ptr(), vec[3].data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(),
                                     L.ptr(dres), dgb[0].data_ptr(),
-                                    dgb[1].data_ptr(), int(direct), L.ptr(cbslot), rows, cs, c, cpad, ctx.act, dtc,
+                                    dgb[1].data_ptr(), int(direct), L.ptr(cbslot), rows, ctx.count,
+                                    1.0 if sync is None else 1.0 / sync.world, cs, c, cpad, ctx.act, dtc,
                                     L.stream()), "bn_bwd_apply")
         if cbslot is not None:
             link.done = True
@@ -512,6 +534,25 @@ def bn_eval_act(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: fl
     L.check(L.load().vg_bn_act_fwd(x.data_ptr(), L.ptr(res), y.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                                    x.numel() // cs, cs, c, act, L.vg_dtype(x.dtype), L.stream()), "bn_act_fwd")
     return y
+
+
+class GradBoundaryFn(torch.autograd.Function):
+    """Identity whose backward calls ``fn()`` first: placed on the tensor that enters a group of layers, it fires
+    when the backward pass has enqueued every gradient kernel of that group (data-parallel bucket boundary)."""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.fn()
+        return g, None
+
+
+def grad_boundary(x: torch.Tensor, fn) -> torch.Tensor:
+    return GradBoundaryFn.apply(x, fn) if (torch.is_grad_enabled() and x.requires_grad) else x
 
 
 class AddFn(torch.autograd.Function):
@@ -557,6 +598,8 @@ class VectorQuantizeFn(torch.autograd.Function):
         L.check(lib.vg_vq_gather(flat.data_ptr(), codebook.data_ptr(), idx.data_ptr(), rows, k, d, zq_flat.data_ptr(),
                                  scal.data_ptr(), L.ptr(counts), L.ptr(esum), L.stream()), "vq_gather")
         if training:
+            if STAT_SYNC[0] is not None:
+                STAT_SYNC[0].sum_(buf[:k * (d + 1)])        # counts and embedded sums of the global batch
             L.check(lib.vg_vq_ema_update(ema_cluster.data_ptr(), ema_w.data_ptr(), codebook.data_ptr(), counts.data_ptr(),
                                          esum.data_ptr(), k, d, decay, nsum.data_ptr(), L.stream()), "vq_ema_update")
         zq = torch.empty_like(z)

@@ -24,29 +24,128 @@ def build_optimizers(model, config):
 
 
 class DataParallel:
-    """Gradient exchange for one process per GPU.  ``reduce(opt)`` averages ``opt.flat_g`` over the
-    group in ``n_slices`` contiguous all-reduces (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+    """Data parallelism for one process per GPU (RCCL over xGMI on GPUs, gloo in the CPU tests).
 
-    def __init__(self, group=None, slice_bytes: int = 64 << 20):
+    Gradient exchange.  Every optimizer keeps its gradients in one flat buffer (``FlatAdam.flat_g``), so a bucket is
+    a contiguous slice of it: no packing copies.  ``mark(x, opt, params)`` puts a boundary on the tensor that enters
+    a group of layers; when the backward pass reaches it, the gradient kernels of that group have all been enqueued
+    and the slice that holds ``params`` is all-reduced on the communication stream, in ``bucket_bytes`` pieces,
+    while the rest of the backward pass still runs on the compute stream.  ``reduce(opt)`` exchanges whatever has
+    not been sent, makes the compute stream wait for all of it and returns 1/world, which the Adam kernel applies
+    (the sum is never divided in memory).
+
+    Statistics.  ``bn_sync='local'``: each rank normalises with the BatchNorm statistics of its own images and
+    feeds its own VQ-EMA counts (DistributedDataParallel semantics).  ``bn_sync='global'``: the statistics of the
+    whole batch are used on every rank (the sums are added over the ranks before they are finalised, forward and
+    backward), which is what the single-device reference computes at the global batch size."""
+
+    def __init__(self, group=None, bucket_bytes: int = 32 << 20, bn_sync: str = "local", slice_bytes: Optional[int] = None):
+        if bn_sync not in ("local", "global"):
+            raise ValueError("bn_sync must be 'local' or 'global'")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.slice_elems = max(1, slice_bytes // 4)
+        self.bucket_elems = max(1, (slice_bytes or bucket_bytes) // 4)
+        self.bn_sync = bn_sync
+        self._sent = {}          # id(opt) -> list of (lo, hi) element ranges already exchanged in this phase
+        self._work = []
+        self._comm = None        # side stream for the collectives (GPU only)
+        if self.world > 1 and bn_sync == "global":
+            ops.STAT_SYNC[0] = self
+        self.n_async = 0         # buckets that were launched from a backward boundary (tests / diagnostics)
+        # gloo (CPU tests, or several ranks sharing one GPU in the GPU test) moves device tensors through the host
+        self._staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
+    # ---- global-batch statistics (ops.STAT_SYNC interface)
+    def sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            if self._staged and t.is_cuda:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def close(self):
+        if ops.STAT_SYNC[0] is self:
+            ops.STAT_SYNC[0] = None
+
+    # ---- parameters
     def broadcast_model(self, model):
         if self.world == 1:
             return
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src=0, group=self.group)
+            if self._staged and t.is_cuda:
+                h = t.data.cpu()
+                dist.broadcast(h, src=0, group=self.group)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, src=0, group=self.group)
 
-    def reduce(self, opt: FlatAdam):
+    # ---- gradient buckets
+    @staticmethod
+    def span(opt: FlatAdam, params) -> tuple:
+        """Element range [lo, hi) of ``opt.flat_g`` that holds exactly the gradients of ``params``
+        (they must be adjacent in the optimizer's parameter order)."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(opt.params) if id(p) in ids]
+        if not idx:
+            return (0, 0)
+        if idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError("bucket parameters are not contiguous in the optimizer's flat buffer")
+        lo = opt.offsets[idx[0]]
+        hi = opt.offsets[idx[-1] + 1] if idx[-1] + 1 < len(opt.params) else opt.numel
+        return (lo, hi)
+
+    def _send(self, opt, lo: int, hi: int):
+        if hi <= lo or self.world == 1:
+            return
+        flat = opt.flat_g
+        self._sent.setdefault(id(opt), []).append((lo, hi))
+        if flat.is_cuda and self._staged:
+            self.sum_(flat[lo:hi])
+        elif flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=flat.device)
+            ev = torch.cuda.Event()
+            ev.record()                          # every gradient kernel enqueued so far on the compute stream
+            self._comm.wait_event(ev)
+            with torch.cuda.stream(self._comm):
+                for s in range(lo, hi, self.bucket_elems):
+                    self._work.append(dist.all_reduce(flat[s:min(s + self.bucket_elems, hi)], op=dist.ReduceOp.SUM,
+                                                      group=self.group, async_op=True))
+        else:
+            for s in range(lo, hi, self.bucket_elems):
+                self._work.append(dist.all_reduce(flat[s:min(s + self.bucket_elems, hi)], op=dist.ReduceOp.SUM,
+                                                  group=self.group, async_op=True))
+
+    def mark(self, x: torch.Tensor, opt: FlatAdam, params) -> torch.Tensor:
+        """Boundary on ``x``, the input of the layers that own ``params``: their slice is exchanged as soon as the
+        backward pass gets here."""
+        if self.world == 1:
+            return x
+        lo, hi = self.span(opt, list(params))
+
+        def fire():
+            self.n_async += 1
+            self._send(opt, lo, hi)
+        return ops.grad_boundary(x, fire)
+
+    def reduce(self, opt: FlatAdam) -> float:
         if self.world == 1:
             return 1.0
-        flat = opt.flat_g
-        handles = []
-        for s in range(0, flat.numel(), self.slice_elems):
-            handles.append(dist.all_reduce(flat[s:s + self.slice_elems], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for h in handles:
-            h.wait()
+        done = sorted(self._sent.get(id(opt), []))
+        pos = 0
+        for lo, hi in done + [(opt.flat_g.numel(), opt.flat_g.numel())]:
+            if lo > pos:
+                self._send(opt, pos, lo)
+            pos = max(pos, hi)
+        for w in self._work:
+            w.wait()                              # GPU: the compute stream waits for the collective, the host does not
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        self._work.clear()
+        self._sent[id(opt)] = []
         return 1.0 / self.world      # folded into the Adam kernel as grad_scale
 
 
@@ -97,6 +196,8 @@ def vq_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optional[
     with ops.step_scope(images.device):
         if share_encoder:
             z_q, vq_loss, indices = model.vector_quantizer(z, training=True)
+            if dp:      # decoder gradients are complete when the backward pass reaches z_q: exchange them under the
+                z_q = dp.mark(z_q, opt_g, model.decoder.parameters())      # encoder's backward
             recon = model.decoder(z_q)
         else:
             recon, _, _, vq_loss, indices = model(images)
@@ -115,7 +216,14 @@ def beta_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optiona
     built with recon_target_policy='area' (shim D1)."""
     opt_d.zero_grad()
     with ops.step_scope(images.device):
-        recon, _, mu, logvar = model(images, eps)
+        if dp:      # G-phase backward order: decoder, the two 268 MB Linear layers, the conv features.  Each slice is
+            # exchanged as soon as it is complete, under the backward pass of what comes before it in the network.
+            enc = model.encoder
+            enc.grad_boundary = lambda f: dp.mark(f, opt_g, list(enc.fc_mu.parameters()) + list(enc.fc_logvar.parameters()))
+            z, mu, logvar = model.encode(images, eps)
+            recon = model.decode(dp.mark(z, opt_g, model.decoder.parameters()))
+        else:
+            recon, _, mu, logvar = model(images, eps)
         disc_real = model.discriminator(images)
         disc_fake = model.discriminator(recon.detach())
         d_loss = model.loss_function(images, recon, mu, logvar, disc_real, disc_fake, train_generator=False)
@@ -158,7 +266,10 @@ def hier_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optiona
     with ops.step_scope(images.device):
         if share_encoder:
             eps = eps_lists[1] or [None] * len(mu_list)
-            recon = model.decode([model.reparameterize(m, v, e) for m, v, e in zip(mu_list, logvar_list, eps)])
+            z_list = [model.reparameterize(m, v, e) for m, v, e in zip(mu_list, logvar_list, eps)]
+            if dp:      # the deepest latent enters the decoder first, so its gradient is the decoder's last
+                z_list[-1] = dp.mark(z_list[-1], opt_g, model.decoder.parameters())
+            recon = model.decode(z_list)
         else:
             recon, _, mu_list, logvar_list = model(images, eps_lists[1])
         with (frozen(model.discriminator) if elide_d_wgrad else contextlib.nullcontext()):
