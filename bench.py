@@ -56,6 +56,11 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--arch", default="vq", choices=["vq", "beta", "hier"],
+                    help="vq = BASELINE.json configs[1] (the driver's line); beta / hier = configs[2] / configs[3] per GPU, "
+                         "with the documented non-reference shims D1 / D2 (the reference step raises without them)")
+    ap.add_argument("--num-embeddings", type=int, default=512)
+    ap.add_argument("--embedding-dim", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-shapes", action="store_true", help="key the live kernel timings by layer shape too")
@@ -72,15 +77,43 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from vae_gan_amd import ops
-    from vae_gan_amd.train import DataParallel, build_optimizers, vq_train_step
-    from vae_gan_amd.vq_vae_gan.config import Config
-    from vae_gan_amd.vq_vae_gan.model import VQVAEGAN
+    from vae_gan_amd import train as T
+    from vae_gan_amd.train import DataParallel, build_optimizers
 
     ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    cfg = Config()
-    cfg.image_size, cfg.batch_size = args.size, args.batch
     torch.manual_seed(42)
-    model = VQVAEGAN(cfg).cuda().train()
+    if args.arch == "vq":
+        from vae_gan_amd.vq_vae_gan.config import Config
+        from vae_gan_amd.vq_vae_gan.model import VQVAEGAN
+        cfg = Config()
+        cfg.num_embeddings, cfg.embedding_dim = args.num_embeddings, args.embedding_dim
+        model_cls, step_fn = VQVAEGAN, T.vq_train_step
+        workload = (f"VQ-VAE-GAN train step (D step + G step), num_embeddings={cfg.num_embeddings} "
+                    f"embedding_dim={cfg.embedding_dim} commitment_cost=0.25")
+    elif args.arch == "beta":
+        from vae_gan_amd.beta_vae_gans.config import Config
+        from vae_gan_amd.beta_vae_gans.model import BetaVAEGAN
+        cfg = Config()
+        cfg.recon_target_policy = "area"
+        model_cls, step_fn = BetaVAEGAN, T.beta_train_step
+        workload = "beta-VAE-GAN train step (latent 128; NON-REFERENCE shim D1: area-downsampled target)"
+    else:
+        from vae_gan_amd.hierarchical_vae_gan.config import Config
+        from vae_gan_amd.hierarchical_vae_gan.model import HierarchicalVAEGAN
+        cfg = Config()
+        cfg.recon_target_policy, cfg.hier_decoder_policy = "area", "nearest"
+        model_cls, step_fn = HierarchicalVAEGAN, T.hier_train_step
+        workload = "hierarchical VAE-GAN train step (3 levels, self-attention; NON-REFERENCE shims D2 + D1)"
+    cfg.image_size, cfg.batch_size = args.size, args.batch
+    model = model_cls(cfg).cuda().train()
+    if args.arch == "hier":     # the reference initialises every attention gate to 0 (identity block): open them
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("gamma"):
+                p_.data.fill_(0.1)
+
+    def vq_train_step(model, images, opt_g, opt_d, dp):
+        out = step_fn(model, images, opt_g, opt_d, dp)
+        return out[0], out[1], None
     dp = DataParallel() if world > 1 else None
     if dp:
         dp.broadcast_model(model)
@@ -130,6 +163,9 @@ def main():
 
     if rank == 0:
         imgs_per_s = world * args.batch * args.steps / dt
+        # SURVEY.md §8(a) necessary work per image and train step (known for the 256x256 default shapes only)
+        gf_img = {"vq": GF_PER_IMG_NECESSARY, "beta": 209.2}.get(args.arch) if (
+            args.size == 256 and args.num_embeddings == 512 and args.embedding_dim == 64) else None
         roof = None
         kernels = {}
         if prof is not None:
@@ -157,16 +193,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "VQ-VAE-GAN train step (D step + G step), num_embeddings=512 embedding_dim=64 "
-                                   f"commitment_cost=0.25, {args.size}x{args.size} RGB, random-init weights",
+            "config": {"workload": f"{workload}, {args.size}x{args.size} RGB, random-init weights",
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}"},
-            "step_tflops_necessary": imgs_per_s * GF_PER_IMG_NECESSARY / 1e3 / world,
-            "step_frac_of_bf16_peak": imgs_per_s * GF_PER_IMG_NECESSARY / 1e3 / world / PEAK_BF16_TFLOPS,
+            "step_tflops_necessary": imgs_per_s * gf_img / 1e3 / world if gf_img else None,
+            "step_frac_of_bf16_peak": imgs_per_s * gf_img / 1e3 / world / PEAK_BF16_TFLOPS if gf_img else None,
             "losses_finite": finite,
             "roofline": roof, "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.arch == "vq":
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
             out["cpu_baseline"] = cpu_baseline(16, args.size, threads)
         print(json.dumps(out), flush=True)
