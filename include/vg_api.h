@@ -143,8 +143,11 @@ int vg_add_inplace(void* a, const void* b, int64_t n, int dtype, void* stream);
 
 /* ---- Vector quantiser (vq_vae_gan/model.py:68-134) ---------------------------------------- */
 /* idx[i] = argmin_k (|z_i|^2 + |E_k|^2) - 2 z_i.E_k   in f32, that op order, first-min ties
- * (model.py:88-95).  z: [rows][d] f32 row-major (NHWC flat), codebook [k][d] f32. */
-int vg_vq_assign(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx, void* stream);
+ * (model.py:88-95).  z: [rows][d] f32 row-major (NHWC flat), codebook [k][d] f32.
+ * norms_ws: optional caller-owned scratch of k floats (receives |E_k|^2); with it and d in {64,128,256} the
+ * register-resident search kernel is used (same arithmetic and indices, several times faster on large codebooks). */
+int vg_vq_assign(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx, float* norms_ws,
+                 void* stream);
 /* zq = z + (E[idx] - z); sse += sum (E[idx]-z)^2 (f64 scalar, zeroed by caller); optional EMA
  * statistics counts[k] (f32) and esum[k][d] (f32), zeroed by caller (model.py:98-119). */
 int vg_vq_gather(const float* z, const float* codebook, const int64_t* idx, int64_t rows, int k, int d, float* zq,

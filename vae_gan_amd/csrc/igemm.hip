@@ -1040,6 +1040,7 @@ extern "C" void vg_set_conv_kernel(int version) {
 template <typename T> static int dispatch_igemm2(const IgemmParams& p, hipStream_t st, bool* handled) {
   *handled = false;
   if (!g_use_igemm2 || p.ksplit > 1 || p.in_s != 1) return VG_OK;   // stride-2 gathers: the im2col-row kernel is faster
+  if (p.OHl * p.OWl == 1) return VG_OK;   // Linear layers ([B,1,1,F] "images"): one spatial tile per image would be 1 pixel wide
   if (p.in_s == 1) {
     if (p.Npad % 128 == 0) return launch_igemm2<T, 2, 2, 4, 2, 16>(p, st, handled);
     if (p.Npad == 64) return launch_igemm2<T, 2, 2, 4, 1, 16>(p, st, handled);

@@ -80,11 +80,129 @@ __global__ __launch_bounds__(NW * 64) void vq_assign_kernel(const float* __restr
   if (h == 0 && row < rows) idx[row] = besti;
 }
 
+// ---------------------------------------------------------------------------------------------
+// vq_assign2: the same arithmetic (same k order, same tie rule, so the same indices bit for bit) laid out for large
+// codebooks (K = 8192, D = 256: 275 GFLOP per search at batch 16 x 64 x 64 latents).  The kernel above keeps z and
+// the code tile in LDS, reads two scalars per MFMA, and at D = 256 fits one 2-wave block per CU.  Here
+//  * a wave's 32 z rows live in REGISTERS for the whole search (D/2 VGPRs: lane (h, row) holds z[row][2s+h]),
+//  * the code tile is stored [code][k parity][D/2] so one ds_read_b128 feeds four MFMAs,
+//  * |E_k|^2 comes from a one-thread-per-code pre-pass (same sequential sum) instead of 32 lanes per tile,
+//  * the next tile's global loads are issued before the MFMA loop and land in LDS after it,
+// which leaves 67 KB of LDS per 4-wave block: two blocks per CU, two waves on every SIMD.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restrict__ cb, int K, int D, float* __restrict__ e2) {
+  const int code = blockIdx.x * 256 + threadIdx.x;
+  if (code >= K) return;
+  const float* er = cb + (size_t)code * D;
+  float s = 0.f;
+  for (int k = 0; k < D; ++k) s += er[k] * er[k];
+  e2[code] = s;
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void vq_assign2_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                         const float* __restrict__ e2, int64_t rows, int K,
+                                                         int64_t* __restrict__ idx) {
+  constexpr int HD = D / 2, LDW = HD + 4, NV = D / 32;     // NV: f32x4 staging loads per thread per tile
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* se = sm;                              // [2][32][2][LDW]
+  float* sb = sm + 2 * 32 * 2 * LDW;           // [2][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31;
+  const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + l32;
+
+  float zr[HD];
+  float zz = 0.f;
+  {
+    const float* zp = z + (size_t)(row < rows ? row : rows - 1) * D;
+#pragma unroll
+    for (int c4 = 0; c4 < D / 4; ++c4) {
+      const f32x4 v = *(const f32x4*)(zp + c4 * 4);
+      zz += v[0] * v[0]; zz += v[1] * v[1]; zz += v[2] * v[2]; zz += v[3] * v[3];
+      zr[2 * c4] = h ? v[1] : v[0];
+      zr[2 * c4 + 1] = h ? v[3] : v[2];
+      if (c4 % 8 == 7) __builtin_amdgcn_sched_barrier(0);      // keep at most 8 row loads in flight (register pressure)
+    }
+  }
+  const int ntiles = (K + 31) / 32;
+  f32x4 pre[NV];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = i * 256 + tid, r = q / (D / 4), c4 = q % (D / 4);
+      const int code = tile * 32 + r;
+      pre[i] = code < K ? *(const f32x4*)(cb + (size_t)code * D + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto put = [&](int tile, int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = i * 256 + tid, r = q / (D / 4), c4 = q % (D / 4);
+      float* d0 = se + ((buf * 32 + r) * 2) * LDW + 2 * c4;
+      *(f32x2*)d0 = f32x2{pre[i][0], pre[i][2]};
+      *(f32x2*)(d0 + LDW) = f32x2{pre[i][1], pre[i][3]};
+    }
+    if (tid < 32) sb[buf * 32 + tid] = tile * 32 + tid < K ? e2[tile * 32 + tid] : 0.f;
+  };
+  fetch(0);
+  put(0, 0);
+  __syncthreads();
+
+  float best = __builtin_inff();
+  int besti = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch(t + 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ea = se + ((buf * 32 + l32) * 2 + h) * LDW;
+#pragma unroll
+    for (int s4 = 0; s4 < HD / 4; ++s4) {
+      const f32x4 a = *(const f32x4*)(ea + 4 * s4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], zr[4 * s4 + i], acc, 0, 0, 0);
+      if (s4 % 4 == 3) __builtin_amdgcn_sched_barrier(0);      // at most four fragment vectors hoisted ahead
+    }
+    if (t + 1 < ntiles) put(t + 1, buf ^ 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const int code = t * 32 + cl;
+      const float dist = (zz + sb[buf * 32 + cl]) - 2.f * acc[r];
+      if (code < K && dist < best) { best = dist; besti = code; }
+    }
+    __syncthreads();
+  }
+  const float ob = __shfl_xor(best, 32, 64);
+  const int oi = __shfl_xor(besti, 32, 64);
+  if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  if (h == 0 && row < rows) idx[row] = besti;
+}
+
+template <int D>
+static int launch_vq_assign2(const float* z, const float* cb, float* e2, int64_t rows, int k, int64_t* idx, hipStream_t st) {
+  constexpr size_t lds = (size_t)(2 * 32 * 2 * (D / 2 + 4) + 64) * sizeof(float);
+  static bool set = false;
+  if (!set) { VG_HIP(hipFuncSetAttribute((const void*)vq_assign2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+  hipLaunchKernelGGL(vq_code_norms_kernel, dim3((unsigned)vg_ceil_div(k, 256)), dim3(256), 0, st, cb, k, D, e2);
+  VG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vq_assign2_kernel<D>, dim3((unsigned)vg_ceil_div(rows, 128)), dim3(256), lds, st, z, cb, (const float*)e2, rows, k, idx);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
 extern "C" int vg_vq_assign(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx,
-                            void* stream) {
+                            float* norms_ws, void* stream) {
   VG_REQUIRE(z && codebook && idx && rows > 0 && k > 0, "vq_assign: bad arguments");
   VG_REQUIRE(d % 4 == 0 && d >= 4 && d <= 256, "vq_assign: embedding_dim %d unsupported (multiple of 4, <= 256)", d);
   hipStream_t st = (hipStream_t)stream;
+  if (norms_ws != nullptr) {
+    if (d == 64) return launch_vq_assign2<64>(z, codebook, norms_ws, rows, k, idx, st);
+    if (d == 128) return launch_vq_assign2<128>(z, codebook, norms_ws, rows, k, idx, st);
+    if (d == 256) return launch_vq_assign2<256>(z, codebook, norms_ws, rows, k, idx, st);
+  }
   const int nw = d <= 128 ? 4 : 2;
   const size_t lds = ((size_t)(nw * 32 + 64) * (d + 1) + 64) * sizeof(float);
   const unsigned blocks = (unsigned)vg_ceil_div(rows, nw * 32);

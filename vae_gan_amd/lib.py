@@ -59,7 +59,7 @@ SIGNATURES = {
     "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _F, _I, _I, _I, _I, _I, _P]),
     "vg_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "vg_add_inplace": (_I, [_P, _P, _L, _I, _P]),
-    "vg_vq_assign": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "vg_vq_assign": (_I, [_P, _P, _L, _I, _I, _P, _P, _P]),
     "vg_vq_gather": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "vg_vq_ema_update": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "vg_vq_bwd": (_I, [_P, _P, _P, _P, _L, _F, _P, _P]),

@@ -588,7 +588,9 @@ class VectorQuantizeFn(torch.autograd.Function):
         flat = torch.empty(rows, d, dtype=torch.float32, device=dev)
         L.check(lib.vg_nchw_to_nhwc(z.data_ptr(), flat.data_ptr(), b, d, h, w, d, L.VG_F32, L.stream()), "vq.flatten")
         idx = torch.empty(rows, dtype=torch.int64, device=dev)
-        L.check(lib.vg_vq_assign(flat.data_ptr(), codebook.data_ptr(), rows, k, d, idx.data_ptr(), L.stream()), "vq_assign")
+        norms = torch.empty(k, dtype=torch.float32, device=dev)
+        L.check(lib.vg_vq_assign(flat.data_ptr(), codebook.data_ptr(), rows, k, d, idx.data_ptr(), norms.data_ptr(),
+                                 L.stream()), "vq_assign")
         zq_flat = torch.empty_like(flat)
         scal = torch.zeros(2, dtype=torch.float64, device=dev)       # [sse, unused]
         counts = esum = None
