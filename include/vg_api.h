@@ -197,6 +197,15 @@ int vg_attn_fwd(const float* q, const float* k, const float* v, float* o, float*
 /* Gradients of the above w.r.t. q, k, v given d_o; delta_ws: b*hw f32 of scratch. */
 int vg_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
                 float* dq, float* dk, float* dv, float* delta_ws, int b, int hw, int d, int c, void* stream);
+/* The same attention on the bf16 MFMA (v_mfma_f32_32x32x16_bf16), for the bf16 compute mode: q, k [b*hw][32] and
+ * v [b*hw][c] are the bf16 NHWC tensors the 1x1 convs wrote (q/k channels beyond the real width are zero padding),
+ * o / d_o / dq / dk / dv stay f32.  Scores are exact products of the stored bf16 values; P and dS are rounded to bf16
+ * once.  vg_attn_supported_bf16 says whether a shape is covered (hw % 128 == 0, d == 32, c in {128, 256}). */
+int vg_attn_supported_bf16(int hw, int d, int c);
+int vg_attn_fwd_bf16(const void* q, const void* k, const void* v, float* o, float* lse, int b, int hw, int d, int c,
+                     void* stream);
+int vg_attn_bwd_bf16(const void* q, const void* k, const void* v, const float* o, const float* d_o, const float* lse,
+                     float* dq, float* dk, float* dv, float* delta_ws, int b, int hw, int d, int c, void* stream);
 /* y = gamma[0]*o + x (model.py:45); backward: d_o = gamma*gy, dgamma[0] (f64, zeroed by caller) += sum gy*o. */
 int vg_gamma_residual(const float* o, const float* x, const float* gamma, float* y, int64_t n, void* stream);
 int vg_gamma_residual_bwd(const float* gy, const float* o, const float* gamma, float* d_o, double* dgamma, int64_t n,

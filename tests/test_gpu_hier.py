@@ -131,3 +131,63 @@ def test_hier_full_step_matches_reference(vg, share):
              "recon": float(gl["recon"]), "kl": float(gl["kl"]), "adv": float(gl["adv"]), "recon_img": recon.detach().cpu()}
         check_step(g, it, r, ("d_loss", "d_kl", "g_loss", "recon", "kl", "adv"))
     check_state(g, {k: v.detach().cpu() for k, v in model.state_dict().items()}, max(float(g["noise:it1_recon_img"]), 1e-4))
+
+
+@pytest.mark.parametrize("c,hw,b", [(128, 512, 2), (256, 256, 2), (128, 4096, 1)])
+def test_bf16_attention_kernels_match_exact_f32_kernels(vg, c, hw, b):
+    """vg_attn_fwd_bf16 / vg_attn_bwd_bf16 (bf16 MFMA, transposed LDS reads) against the exact-f32 MFMA kernels on the
+    SAME bf16-representable q, k, v: scores are exact products either way, so only P and dS are rounded (2^-9)."""
+    from vae_gan_amd import lib as L
+    lib = L.load()
+    g = torch.Generator(device="cuda").manual_seed(c + hw)
+    d = 32
+    width = c // 8
+    q = torch.zeros(b, hw, d, device="cuda")
+    k = torch.zeros(b, hw, d, device="cuda")
+    q[..., :width] = 0.6 * torch.randn(b, hw, width, device="cuda", generator=g)
+    k[..., :width] = 0.6 * torch.randn(b, hw, width, device="cuda", generator=g)
+    v = torch.randn(b, hw, c, device="cuda", generator=g)
+    d_o = torch.randn(b, hw, c, device="cuda", generator=g)
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    qf, kf, vf = qb.float(), kb.float(), vb.float()
+    assert lib.vg_attn_supported_bf16(hw, d, c)
+
+    def run(fwd, bwd, qq, kk, vv):
+        o = torch.empty(b, hw, c, device="cuda")
+        lse = torch.empty(b * hw, device="cuda")
+        L.check(fwd(qq.data_ptr(), kk.data_ptr(), vv.data_ptr(), o.data_ptr(), lse.data_ptr(), b, hw, d, c, L.stream()), "fwd")
+        dq, dk, dv = torch.empty(b, hw, d, device="cuda"), torch.empty(b, hw, d, device="cuda"), torch.empty(b, hw, c, device="cuda")
+        ws = torch.empty(b * hw, device="cuda")
+        L.check(bwd(qq.data_ptr(), kk.data_ptr(), vv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), dq.data_ptr(),
+                    dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), b, hw, d, c, L.stream()), "bwd")
+        torch.cuda.synchronize()
+        return o, lse, dq, dk, dv
+    fast = run(lib.vg_attn_fwd_bf16, lib.vg_attn_bwd_bf16, qb, kb, vb)
+    ref = run(lib.vg_attn_fwd, lib.vg_attn_bwd, qf, kf, vf)
+    for name, a, r, tol in zip(("o", "lse", "dq", "dk", "dv"), fast, ref, (4e-3, 1e-5, 1e-2, 1e-2, 6e-3)):
+        close_l2(a, r.cpu(), rtol=tol, what=f"attn_bf16.{name}")
+    if width < d:      # zero-padded q/k channels get exactly zero gradients
+        assert float(fast[2][..., width:].abs().max()) == 0.0 and float(fast[3][..., width:].abs().max()) == 0.0
+
+
+def test_self_attention_module_bf16_mode(vg):
+    """SelfAttention(128) in the bf16 compute mode (bf16 MFMA attention kernels) against the reference golden:
+    north_star's bf16 tolerance, 2e-2."""
+    from vae_gan_amd.hierarchical_vae_gan.model import SelfAttention
+    vg.set_compute_dtype(torch.bfloat16)
+    try:
+        g = load_golden("hier_attention128")
+        sa = _filled(SelfAttention(128)).cuda().train()
+        x = as_t(g["x"]).cuda().requires_grad_(True)
+        y = vg.to_nchw(sa(vg.to_nhwc(x)), 128)
+        (y * as_t(g["cot0"]).cuda()).sum().backward()
+        torch.cuda.synchronize()
+        close_l2(y, g["y0"], rtol=2e-2, what="attn128.bf16.y")
+        close_l2(x.grad, g["dx"], rtol=2e-2, what="attn128.bf16.dx")
+        from vae_gan_amd.testing import digest
+        for key, ref in g.items():
+            if key.startswith("gd:") and key.endswith(("weight", "gamma")):
+                mine = digest(key[3:], dict(sa.named_parameters())[key[3:]].grad)
+                assert abs(mine[0] - ref[0]) <= 3e-2 * ref[0], (key, mine[0], ref[0])
+    finally:
+        vg.set_compute_dtype(torch.float32)

@@ -74,6 +74,9 @@ SIGNATURES = {
     "vg_scalar_finish": (_I, [_P, _D, _P, _P]),
     "vg_attn_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vg_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vg_attn_supported_bf16": (_I, [_I, _I, _I]),
+    "vg_attn_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vg_attn_bwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "vg_gamma_residual": (_I, [_P, _P, _P, _P, _L, _P]),
     "vg_gamma_residual_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
     "vg_cast": (_I, [_P, _P, _L, _I, _I, _P]),

@@ -876,7 +876,9 @@ def _from_f32(t: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
 
 
 class AttentionFn(torch.autograd.Function):
-    """out = gamma * softmax(q k^T) v + x on NHWC tensors [B,H,W,*] (q,k: [..,dqk_s], v,x: [..,cs])."""
+    """out = gamma * softmax(q k^T) v + x on NHWC tensors [B,H,W,*] (q,k: [..,dqk_s], v,x: [..,cs]).
+    bf16 mode: the products run on the bf16 MFMA straight from the bf16 tensors (vg_attn_*_bf16) where the shape is
+    covered; otherwise, and always in f32 mode, on the exact-f32 MFMA."""
 
     @staticmethod
     def forward(ctx, q, k, v, x, gamma):
@@ -885,16 +887,23 @@ class AttentionFn(torch.autograd.Function):
         dt = x.dtype
         b, hh, ww, cs = v.shape
         hw, d = hh * ww, q.shape[-1]
-        qf, kf, vf, xf = _to_f32(q), _to_f32(k), _to_f32(v), _to_f32(x)
-        o = torch.empty_like(vf)
+        fast = dt == torch.bfloat16 and bool(lib.vg_attn_supported_bf16(hw, d, cs))
+        xf = _to_f32(x)
+        o = torch.empty(b, hh, ww, cs, dtype=torch.float32, device=q.device)
         lse = torch.empty(b * hw, dtype=torch.float32, device=q.device)
-        L.check(lib.vg_attn_fwd(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), o.data_ptr(), lse.data_ptr(), b, hw, d, cs,
-                                L.stream()), "attn_fwd")
-        y = torch.empty_like(vf)
+        if fast:
+            qf, kf, vf = q.contiguous(), k.contiguous(), v.contiguous()
+            L.check(lib.vg_attn_fwd_bf16(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), o.data_ptr(), lse.data_ptr(), b, hw, d, cs,
+                                         L.stream()), "attn_fwd_bf16")
+        else:
+            qf, kf, vf = _to_f32(q), _to_f32(k), _to_f32(v)
+            L.check(lib.vg_attn_fwd(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), o.data_ptr(), lse.data_ptr(), b, hw, d, cs,
+                                    L.stream()), "attn_fwd")
+        y = torch.empty_like(o)
         gam = gamma.detach().float().contiguous()
         L.check(lib.vg_gamma_residual(o.data_ptr(), xf.data_ptr(), gam.data_ptr(), y.data_ptr(), y.numel(), L.stream()), "gamma_residual")
         ctx.save_for_backward(qf, kf, vf, o, lse, gam)
-        ctx.dt, ctx.dims = dt, (b, hw, d, cs)
+        ctx.dt, ctx.dims, ctx.fast = dt, (b, hw, d, cs), fast
         return _from_f32(y, dt)
 
     @staticmethod
@@ -907,10 +916,13 @@ class AttentionFn(torch.autograd.Function):
         dgam = torch.zeros(1, dtype=torch.float64, device=o.device)
         L.check(lib.vg_gamma_residual_bwd(gyf.data_ptr(), o.data_ptr(), gam.data_ptr(), d_o.data_ptr(), dgam.data_ptr(),
                                           o.numel(), L.stream()), "gamma_residual_bwd")
-        dq, dk, dv = torch.empty_like(qf), torch.empty_like(kf), torch.empty_like(vf)
+        dq = torch.empty(qf.shape, dtype=torch.float32, device=o.device)
+        dk = torch.empty(kf.shape, dtype=torch.float32, device=o.device)
+        dv = torch.empty(vf.shape, dtype=torch.float32, device=o.device)
         ws = torch.empty(b * hw, dtype=torch.float32, device=o.device)
-        L.check(lib.vg_attn_bwd(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
-                                dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), b, hw, d, cs, L.stream()), "attn_bwd")
+        fn = lib.vg_attn_bwd_bf16 if ctx.fast else lib.vg_attn_bwd
+        L.check(fn(qf.data_ptr(), kf.data_ptr(), vf.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+                   dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), b, hw, d, cs, L.stream()), "attn_bwd")
         dgamma = torch.empty(1, dtype=torch.float32, device=o.device)
         L.check(lib.vg_scalar_finish(dgam.data_ptr(), 1.0, dgamma.data_ptr(), L.stream()), "dgamma")
         dt = ctx.dt
