@@ -157,7 +157,9 @@ class PackedWeights:
 
     def get(self, weight: torch.Tensor, desc: L.ConvDesc, transposed: int, dt: torch.dtype) -> torch.Tensor:
         key = (transposed, dt, desc.stride, desc.pad)
-        tag = (weight._version, PARAM_EPOCH[0], weight.data_ptr())
+        # a fused optimizer bumps the epoch cell it shares with ITS parameters (the D step does not invalidate the
+        # generator's packed weights and vice versa); everything else shows up in torch's version counter
+        tag = (weight._version, getattr(weight, "_vg_epoch", PARAM_EPOCH)[0], weight.data_ptr())
         hit = self.cache.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]

@@ -41,6 +41,10 @@ class FlatAdam:
             self.flat_p[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.flat_p[o:o + n].view(p.shape)
             p.grad = self.flat_g[o:o + n].view(p.shape)
+        # packed-weight caches (ops.PackedWeights) of these parameters are keyed on this cell: bumped by step()
+        self._epoch = [ops.PARAM_EPOCH[0] + 1]
+        for p in self.params:
+            p._vg_epoch = self._epoch
         ops.PARAM_EPOCH[0] += 1
 
     # torch.optim surface used by the training loop
@@ -55,7 +59,7 @@ class FlatAdam:
         L.check(L.load().vg_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                       self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1],
                                       self.eps, self.step_count, grad_scale, L.stream()), "adam_step")
-        ops.PARAM_EPOCH[0] += 1
+        self._epoch[0] += 1
 
     @property
     def param_groups(self):
