@@ -326,7 +326,9 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   VG_LAUNCH_CHECK();
   const int ppr = cs / piece;
   const int64_t np = rows;
-  dim3 g(row_blocks(rows, 256 / ppr, 8)), b(256);
+  int nblocks = row_blocks(rows, 256 / ppr, 8);
+  if (dxsum != nullptr && nblocks > 1024) nblocks = 1024;      // every block ends with c same-address f32 atomics
+  dim3 g(nblocks), b(256);
 #define VG_BN_APPLY(T, DR, XM)                                                                                      \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DR, XM>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
                      scale, shift, coef, (T*)dx, (T*)dres, dxsum, np, ppr, c, cpad, act)

@@ -44,6 +44,7 @@ class DataParallel:
             raise ValueError("bn_sync must be 'local' or 'global'")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.bucket_elems = max(1, (slice_bytes or bucket_bytes) // 4)
         self.bn_sync = bn_sync
         self._sent = {}          # id(opt) -> list of (lo, hi) element ranges already exchanged in this phase
