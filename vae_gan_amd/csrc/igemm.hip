@@ -572,6 +572,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm2_kernel(const IgemmParams 
 }
 
 static int g_dbg = 0;   // timing ablations (vg_set_conv_kernel bits 8+)
+#ifdef VG_ABLATE
+static void* g_stamp_buf = nullptr;     // ablation build: per-block s_memtime stamps of igemm3 (dbg bit 8)
+extern "C" void vg_dbg_set_stamp_buffer(void* p) { g_stamp_buf = p; }
+#endif
 template <typename T, int MI, int NI, int WM, int WN, int TH>
 static int launch_igemm2(const IgemmParams& p0, hipStream_t st, bool* handled) {
   IgemmParams p = p0;
@@ -681,6 +685,13 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // SGPR: everything derived from it stays scalar
+#ifdef VG_ABLATE   // per-block s_memtime stamps (shader cycles) of the kernel's stages: tests/gpu_conv_stamps.py
+  unsigned long long* stamps = (VG_DBG(8) && p.splitws) ? (unsigned long long*)p.splitws + (size_t)blockIdx.x * 8 : nullptr;
+#define VG_STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VG_STAMP(i) do {} while (0)
+#endif
+  VG_STAMP(0);
   const int group = wave >> 2;
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l32 = lane & 31;
@@ -785,6 +796,7 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
     halo_rounds(t0, 1, NSH > 1 ? HBYTES : 0);
   }
   __syncthreads();                                   // drains the prologue DMA once; zero fill and rowpix visible
+  VG_STAMP(1);
   if (group == 1 && !VG_DBG(2)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
 
   int cbs = 0;                         // weight slot of the tile being computed
@@ -841,6 +853,7 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
   if (group == 0 && !VG_DBG(2)) __builtin_amdgcn_s_barrier();     // both groups have now passed the same number of barriers
   wait_vmcnt<0>();   // weight tiles prefetched past the end
   __syncthreads();   // every fragment read is done before the staging area aliases the rings
+  VG_STAMP(2);
 
   // ---- epilogue: bias, BN statistics, activation; each wave stages one 32-row block (= one tile row) at a time in T.
   // The common case (tile and channel block fully inside, no sigmoid) runs a lean packed-f32 path: with
@@ -932,6 +945,7 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  VG_STAMP(3);
   if (want_stats) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -953,7 +967,9 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
       unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + n0 + tid], (double)t2);
     }
   }
+  VG_STAMP(4);
 }
+#undef VG_STAMP
 
 template <typename T, int MI, int NI, int WM, int WN, int R, int S>
 static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
@@ -983,6 +999,9 @@ static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
     p.flip = flip;
     if ((size_t)p.N * p.H * p.W * p.Cs * Cfg::EB >= ((size_t)1 << 32)) return VG_OK;   // 32-bit piece offsets
     p.dbg = g_dbg;
+#ifdef VG_ABLATE
+    p.splitws = (float*)g_stamp_buf;
+#endif
     p.tilesX = (int)vg_ceil_div(p.OWl, Cfg::TW);
     p.tilesY = (int)vg_ceil_div(p.OHl, Cfg::TH);
     p.mtiles = p.N * p.tilesX * p.tilesY;
