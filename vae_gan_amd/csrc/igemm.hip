@@ -1255,6 +1255,7 @@ struct WgradParams {
   int otiles, ctiles;
   signed char dy_[VG_MAX_TAPS];
   signed char dx_[VG_MAX_TAPS];
+  int dbg;              // timing ablations only (VG_ABLATE build): 16 = one B fragment for all taps, 32 = no in-loop DMA, 64 = no barrier
 };
 
 // 64-byte-segment swizzle for [pixel][channel] tiles read through ds_read_b64_tr_b16 (bf16 only)
@@ -1599,9 +1600,11 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   }
   int stage = 0;
   for (; t < ntiles; t += G) {
-    if (t + G < ntiles) wait_vmcnt<PR>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if (!VG_DBG(64)) {
+      if (t + G < ntiles) wait_vmcnt<PR>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
     asm volatile("" ::: "memory");
     const bool more = t + 2 * G < ntiles;
     int nimg = 0, nty0 = 0, ntx0 = 0;
@@ -1618,14 +1621,14 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
       const bf16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
 #pragma unroll
       for (int tap = 0; tap < NTAPS; ++tap) {
-        const int hp = (y + tap / 3) * HS + kx * 16 + tap % 3;
+        const int hp = VG_DBG(16) ? (y * HS + kx * 16) : (y + tap / 3) * HS + kx * 16 + tap % 3;
         bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + hp * 64));
         bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64));
         const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
       }
       // prefetch of tile t+2G, spread over the k steps
-      if (more) {
+      if (more && !VG_DBG(32)) {
 #pragma unroll
         for (int r = 0; r < PR; ++r)
           if (r * KSTEPS / PR == kstep) issue_piece(r, nimg, nty0, ntx0, nstage);
@@ -1652,6 +1655,7 @@ template <int NOB, int NCB, int KS>
 static int launch_wgrad3(const WgradParams& p0, hipStream_t st) {
   typedef Wg3Cfg<NOB, NCB, KS> Cfg;
   WgradParams p = p0;
+  p.dbg = g_dbg;
   p.otiles = (int)vg_ceil_div(p.Opad, Cfg::BO);
   p.ctiles = (int)vg_ceil_div(p.Cpad, Cfg::BC);
   const int pairs = p.otiles * p.ctiles;
