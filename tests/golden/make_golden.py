@@ -382,9 +382,52 @@ def g_hier_step():
     print({k: v for k, v in out.items() if k.startswith("noise:")})
 
 
+
+def g_vq_codec():
+    """VQ index entropy coder (vq_vae_gan/model.py:337-576): bitstreams of the REFERENCE ArithmeticEncoder.encode.
+    The reference module never imports numpy (model.py:5-8 vs :378: NameError when called); the harness injects it
+    into the loaded module's namespace, nothing else is touched.  Also records whether the reference's own decode
+    returns the encoded indices (it re-uses the symbol counter as its bit pointer, model.py:491,530-532)."""
+    m = load_ref("vq_vae_gan", "model")
+    m.np = np
+    out = {}
+    cases = [("k512_skewed", 512, (1, 32, 32), 1.5, True), ("k512_uniform_probs", 512, (2, 8, 8), 0.0, False),
+             ("k8192", 8192, (1, 16, 16), 1.2, True), ("k16_tiny", 16, (1, 4, 4), 1.0, True),
+             ("k16_empty", 16, (1, 0, 4), 0.0, False), ("k512_one_symbol", 512, (1, 4, 4), -1.0, True)]
+    for tag, K, shape, zipf, use_hist in cases:
+        g = torch.Generator().manual_seed(len(tag) * 131 + K)
+        if zipf < 0:     # a collapsed codebook: every latent picks the same code (probability exactly 1)
+            idx = torch.full(shape, 37, dtype=torch.int64)
+        elif zipf > 0:     # skewed usage, like a trained codebook
+            w = 1.0 / torch.arange(1, K + 1, dtype=torch.float64) ** zipf
+            idx = torch.multinomial(w / w.sum(), int(np.prod(shape)), replacement=True, generator=g).reshape(shape)
+            idx = idx[..., torch.randperm(idx.shape[-1], generator=g)]
+        else:
+            idx = torch.randint(0, K, shape, generator=g)
+        enc = m.ArithmeticEncoder(K)
+        if use_hist:
+            probs = m.calculate_codebook_usage(idx, K)
+            data = enc.encode(idx, probs)
+            out[f"{tag}:probs"] = probs
+        else:
+            probs = None
+            data = enc.encode(idx)
+        try:
+            back = enc.decode(data, tuple(shape), probs)
+            rt = bool((back == idx).all())
+        except Exception:
+            rt = False
+        out[f"{tag}:idx"] = idx
+        out[f"{tag}:bytes"] = np.frombuffer(bytes(data), dtype=np.uint8)
+        out[f"{tag}:K"] = K
+        out[f"{tag}:ref_decode_roundtrips"] = rt
+        print(tag, "bytes", len(data), "reference decode round-trips:", rt)
+    save("vq_codec", **out)
+
+
 GROUPS = {"vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
           "vq_step": g_vq_step, "losses": g_losses, "beta_modules": g_beta_modules,
-          "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step}
+          "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step, "vq_codec": g_vq_codec}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -113,3 +113,29 @@ def test_beta_full_step_matches_reference(vg):
              "kl": float(gl["kl"]), "adv": float(gl["adv"]), "recon_img": recon.detach().cpu()}
         check_step(g, it, r, ("d_loss", "g_loss", "recon", "kl", "adv"))
     check_state(g, {k: v.detach().cpu() for k, v in model.state_dict().items()}, max(float(g["noise:it1_recon_img"]), 1e-4))
+
+
+def test_beta_step_bf16_close_to_reference(vg):
+    """bf16 mode: first-iteration losses within 2e-2 of the fp32 reference (north_star's bf16 tolerance)."""
+    from vae_gan_amd.beta_vae_gans.config import Config
+    from vae_gan_amd.beta_vae_gans.model import BetaVAEGAN
+    from vae_gan_amd.testing import fill_state_dict, synthetic_images
+    from vae_gan_amd.train import build_optimizers, beta_train_step
+    vg.set_compute_dtype(torch.bfloat16)
+    try:
+        g = load_golden("beta_step_256")
+        cfg = Config()
+        cfg.recon_target_policy = "area"
+        model = BetaVAEGAN(cfg)
+        model.load_state_dict(fill_state_dict(model.state_dict()))
+        model.cuda().train()
+        opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+        images = synthetic_images(2, 256, seed=int(g["images_seed"])).cuda()
+        dl, gl = beta_train_step(model, images, opt_g, opt_d, eps=as_t(g["eps0"]).cuda())
+        torch.cuda.synchronize()
+        for k, v in {"d_loss": dl["total"], "g_loss": gl["total"], "recon": gl["recon"], "kl": gl["kl"]}.items():
+            ref = float(g[f"it0_{k}"])
+            assert abs(float(v.detach()) - ref) <= 2e-2 * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
+        assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    finally:
+        vg.set_compute_dtype(torch.float32)

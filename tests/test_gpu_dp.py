@@ -117,8 +117,22 @@ def _worker_rccl(rank, world, port, out):
         res.append((float(dl["total"].detach()), float(gl["total"].detach()), idx2.cpu(), opt_g.flat_g.clone().cpu(),
                     dp.n_async if dp else 0))
     (d0, g0, i0, f0, _), (d1, g1, i1, f1, n1) = res
-    out[0] = (abs(d0 - d1) <= 1e-5 * abs(d0) and abs(g0 - g1) <= 1e-5 * abs(g0) and bool(torch.equal(i0, i1))
-              and float((f0 - f1).norm() / f0.norm()) < 1e-4 and n1 == 1)
+    checks = {"d_loss": abs(d0 - d1) <= 1e-5 * abs(d0), "g_loss": abs(g0 - g1) <= 1e-5 * abs(g0),
+              "idx": bool(torch.equal(i0, i1)), "grads": float((f0 - f1).norm() / f0.norm()), "n_async": n1}
+    # the exchange itself, exactly: a known buffer through the boundary path and through reduce() comes back unchanged
+    import types
+    dp = DataParallel(bucket_bytes=1 << 16)
+    dp.world = 2
+    n = 100000
+    params = [torch.nn.Parameter(torch.zeros(60000, device="cuda")), torch.nn.Parameter(torch.zeros(40000, device="cuda"))]
+    flat = torch.arange(n, dtype=torch.float32, device="cuda")
+    opt = types.SimpleNamespace(params=params, offsets=[0, 60000], numel=n, flat_g=flat.clone())
+    x = torch.ones(4, device="cuda", requires_grad=True)
+    dp.mark(x * 2.0, opt, params[1:]).sum().backward()          # fires the boundary: slice [60000, 100000) on the side stream
+    scale = dp.reduce(opt)                                        # sends [0, 60000), waits for both
+    torch.cuda.synchronize()
+    checks["exact_identity"] = bool(torch.equal(opt.flat_g, flat)) and scale == 0.5 and dp.n_async == 1
+    out[0] = checks
     dist.destroy_process_group()
 
 
@@ -130,4 +144,8 @@ def test_rccl_stream_path_one_rank():
     import torch.multiprocessing as mp
     out = mp.Manager().dict()
     mp.spawn(_worker_rccl, args=(1, _free_port(), out), nprocs=1, join=True)
-    assert out.get(0) is True, dict(out)
+    c = out.get(0)
+    assert c and c["d_loss"] and c["g_loss"] and c["idx"] and c["grads"] < 3e-2 and c["n_async"] == 1 and c["exact_identity"], c
+    # (two runs of the same step differ by 1e-4..3e-3 in the flat gradient: atomics order -> LeakyReLU sign flips, the
+    #  module-level noise floor of DESIGN.md §2; a broken exchange would be O(1) off, and the synthetic buffer above
+    #  pins the exchange exactly)

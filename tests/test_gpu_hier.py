@@ -191,3 +191,61 @@ def test_self_attention_module_bf16_mode(vg):
                 assert abs(mine[0] - ref[0]) <= 3e-2 * ref[0], (key, mine[0], ref[0])
     finally:
         vg.set_compute_dtype(torch.float32)
+
+
+def test_hier_step_bf16_close_to_reference(vg):
+    """bf16 mode (bf16 MFMA convs and attention): first-iteration generator losses within 2e-2 of the fp32 reference.
+    The discriminator loss is held to 4e-2: with the parity fill (SelfAttention.gamma = 0.7, unit-variance
+    activations) the unscaled attention logits of hierarchical_vae_gan/model.py:37 reach |s| ~ 50, the softmax is
+    nearly one-hot, and bf16 STORAGE of q/k/v moves the hinge loss by 2.3 % — 3.2 % with the exact-f32 attention
+    kernels on the same bf16 tensors (VG_ATTN_F32=1), so it is the activation storage, not the attention arithmetic."""
+    from vae_gan_amd.hierarchical_vae_gan.config import Config
+    from vae_gan_amd.hierarchical_vae_gan.model import HierarchicalVAEGAN
+    from vae_gan_amd.testing import fill_state_dict, hier_step_eps
+    from vae_gan_amd.train import build_optimizers, hier_train_step
+    vg.set_compute_dtype(torch.bfloat16)
+    try:
+        g = load_golden("hier_step_128")
+        cfg = Config()
+        cfg.recon_target_policy, cfg.hier_decoder_policy = "area", "nearest"
+        model = HierarchicalVAEGAN(cfg)
+        model.load_state_dict(fill_state_dict(model.state_dict()))
+        model.cuda().train()
+        opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+        eps = hier_step_eps(2, 128)
+        pair = [[e.cuda() for e in fwd] for fwd in eps[0]]
+        dl, gl = hier_train_step(model, as_t(g["images"]).cuda(), opt_g, opt_d, eps_lists=pair)
+        torch.cuda.synchronize()
+        for k, v in {"d_loss": dl["total"], "d_kl": dl["kl"], "g_loss": gl["total"], "recon": gl["recon"], "kl": gl["kl"]}.items():
+            ref = float(g[f"it0_{k}"])
+            tol = 4e-2 if k == "d_loss" else 2e-2
+            assert abs(float(v.detach()) - ref) <= tol * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
+        assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    finally:
+        vg.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("c,h,w", [(128, 5, 7), (128, 4, 4), (256, 3, 3), (128, 9, 8)])
+def test_self_attention_ragged_sizes_match_oracle(vg, c, h, w):
+    """HW that is not a multiple of the 32-wide key / query tiles (small training crops: 64x64 inputs give the
+    discriminator a 4x4 attention map): the last tile is masked, results against the CPU oracle (torch autograd)."""
+    from oracle import vaegan_oracle as O
+    from vae_gan_amd.hierarchical_vae_gan.model import SelfAttention
+    from vae_gan_amd.testing import synthetic_eps, cotangent
+    sa = _filled(SelfAttention(c)).cuda().train()
+    sd = {"a." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in sa.state_dict().items()}
+    x = synthetic_eps((2, c, h, w), 77)
+    cot = cotangent(f"ragged:{c}:{h}:{w}", (2, c, h, w))
+    xc = x.clone().requires_grad_(True)
+    want = O.self_attention(sd, "a", xc)
+    (want * cot).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = vg.to_nchw(sa(vg.to_nhwc(xg)), c)
+    (y * cot.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    close_l2(y, want.detach(), rtol=1e-4, what="ragged attn y")
+    close_l2(xg.grad, xc.grad, rtol=1e-4, what="ragged attn dx")
+    for name, p in sa.named_parameters():
+        if name == "key.bias":     # q.(k + b) shifts every key's score of a query alike: softmax-invariant, the gradient is rounding noise
+            continue
+        close_l2(p.grad, sd["a." + name].grad, rtol=2e-4, what=name)

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_t(const float* __restrict__ 
   const float* kb = k + (size_t)b * HW * D;
   const float* vb = v + (size_t)b * HW * C;
   float qr[16];
+  const bool q_ok = wave_active && q0 + l32 < HW;        // ragged HW: the last wave's lanes past the end idle
 #pragma unroll
-  for (int u = 0; u < 16; ++u) qr[u] = (wave_active && 2 * u + h < D) ? qb[(size_t)(q0 + l32) * D + 2 * u + h] : 0.f;
+  for (int u = 0; u < 16; ++u) qr[u] = (q_ok && 2 * u + h < D) ? qb[(size_t)(q0 + l32) * D + 2 * u + h] : 0.f;
   f32x16 acc[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
@@ -44,8 +45,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_t(const float* __restrict__ 
   float m = -__builtin_inff(), l = 0.f;
   for (int kt = 0; kt < HW; kt += 32) {
     __syncthreads();
-    for (int e = tid; e < 32 * D; e += NW * 64) { int r = e / D, c = e - r * D; sk[r * LK + c] = kb[(size_t)(kt + r) * D + c]; }
-    for (int e = tid; e < 32 * C; e += NW * 64) { int r = e / C, c = e - r * C; sv[r * LV + c] = vb[(size_t)(kt + r) * C + c]; }
+    for (int e = tid; e < 32 * D; e += NW * 64) { int r = e / D, c = e - r * D; sk[r * LK + c] = kt + r < HW ? kb[(size_t)(kt + r) * D + c] : 0.f; }
+    for (int e = tid; e < 32 * C; e += NW * 64) { int r = e / C, c = e - r * C; sv[r * LV + c] = kt + r < HW ? vb[(size_t)(kt + r) * C + c] : 0.f; }
     __syncthreads();
     if (!wave_active) continue;
     f32x16 st;
@@ -54,6 +55,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_t(const float* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 16; ++u)
       if (2 * u < D) st = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[l32 * LK + 2 * u + h], qr[u], st, 0, 0, 0);
+    if (kt + 32 > HW) {                                   // ragged last key tile: keys past the end get zero weight
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt + rho(r, h) >= HW) st[r] = -__builtin_inff();
+    }
     float mx = st[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_t(const float* __restrict__ 
         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[rho(t, h) * LV + cb * 32 + l32], st[t], acc[cb], 0, 0, 0);
     }
   }
-  if (!wave_active) return;
+  if (!q_ok) return;
   const float inv = 1.f / l;
   float* ob = o + ((size_t)b * HW + q0 + l32) * C;
 #pragma unroll
@@ -124,20 +130,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_t(const float* __restrict
   const float* kb = k + (size_t)b * HW * D;
   const float* vb = v + (size_t)b * HW * C;
   float qr[16];
+  const bool q_ok = wave_active && q0 + l32 < HW;        // ragged HW: lanes past the end idle
 #pragma unroll
-  for (int u = 0; u < 16; ++u) qr[u] = (wave_active && 2 * u + h < D) ? qb[(size_t)(q0 + l32) * D + 2 * u + h] : 0.f;
+  for (int u = 0; u < 16; ++u) qr[u] = (q_ok && 2 * u + h < D) ? qb[(size_t)(q0 + l32) * D + 2 * u + h] : 0.f;
   float* mydo = sdo + wave * 32 * LV;
   if (wave_active)
-    for (int e = lane; e < 32 * C; e += 64) { int r = e / C, c = e - r * C; mydo[r * LV + c] = d_o[((size_t)b * HW + q0 + r) * C + c]; }
-  const float my_lse = wave_active ? lse[(size_t)b * HW + q0 + l32] : 0.f;
-  const float my_delta = wave_active ? delta[(size_t)b * HW + q0 + l32] : 0.f;
+    for (int e = lane; e < 32 * C; e += 64) { int r = e / C, c = e - r * C; mydo[r * LV + c] = q0 + r < HW ? d_o[((size_t)b * HW + q0 + r) * C + c] : 0.f; }
+  const float my_lse = q_ok ? lse[(size_t)b * HW + q0 + l32] : 0.f;
+  const float my_delta = q_ok ? delta[(size_t)b * HW + q0 + l32] : 0.f;
   f32x16 dqa;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqa[r] = 0.f;
   for (int kt = 0; kt < HW; kt += 32) {
     __syncthreads();
-    for (int e = tid; e < 32 * 32; e += NW * 64) { int r = e >> 5, c = e & 31; sk[r * LK + c] = c < D ? kb[(size_t)(kt + r) * D + c] : 0.f; }
-    for (int e = tid; e < 32 * C; e += NW * 64) { int r = e / C, c = e - r * C; sv[r * LV + c] = vb[(size_t)(kt + r) * C + c]; }
+    for (int e = tid; e < 32 * 32; e += NW * 64) { int r = e >> 5, c = e & 31; sk[r * LK + c] = (c < D && kt + r < HW) ? kb[(size_t)(kt + r) * D + c] : 0.f; }
+    for (int e = tid; e < 32 * C; e += NW * 64) { int r = e / C, c = e - r * C; sv[r * LV + c] = kt + r < HW ? vb[(size_t)(kt + r) * C + c] : 0.f; }
     __syncthreads();
     if (!wave_active) continue;
     f32x16 st, dp;
@@ -151,12 +158,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_t(const float* __restrict
     for (int u = 0; u < C / 2; ++u)
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[l32 * LV + 2 * u + h], mydo[l32 * LV + 2 * u + h], dp, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = expf(st[r] - my_lse) * (dp[r] - my_delta);     // dS^T[key][q]
+    for (int r = 0; r < 16; ++r)                                                         // dS^T[key][q]; keys past a ragged end: 0
+      st[r] = kt + rho(r, h) < HW ? expf(st[r] - my_lse) * (dp[r] - my_delta) : 0.f;
     // dQ^T[d][q] += sum_key K[key][d] dS^T[key][q]
 #pragma unroll
     for (int t = 0; t < 16; ++t) dqa = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[rho(t, h) * LK + l32], st[t], dqa, 0, 0, 0);
   }
-  if (!wave_active) return;
+  if (!q_ok) return;
   float* out = dq + ((size_t)b * HW + q0 + l32) * D;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -187,11 +195,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_t(const float* __restric
   const float* qb = q + (size_t)b * HW * D;
   const float* kb = k + (size_t)b * HW * D;
   float kr[16];
+  const bool k_ok = wave_active && k0 + l32 < HW;        // ragged HW: lanes (keys) past the end idle
 #pragma unroll
-  for (int u = 0; u < 16; ++u) kr[u] = (wave_active && 2 * u + h < D) ? kb[(size_t)(k0 + l32) * D + 2 * u + h] : 0.f;
+  for (int u = 0; u < 16; ++u) kr[u] = (k_ok && 2 * u + h < D) ? kb[(size_t)(k0 + l32) * D + 2 * u + h] : 0.f;
   float* myv = svk + wave * 32 * LV;
   if (wave_active)
-    for (int e = lane; e < 32 * C; e += 64) { int r = e / C, c = e - r * C; myv[r * LV + c] = v[((size_t)b * HW + k0 + r) * C + c]; }
+    for (int e = lane; e < 32 * C; e += 64) { int r = e / C, c = e - r * C; myv[r * LV + c] = k0 + r < HW ? v[((size_t)b * HW + k0 + r) * C + c] : 0.f; }
   f32x16 dva[NCB], dka;
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
@@ -201,10 +210,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_t(const float* __restric
   for (int r = 0; r < 16; ++r) dka[r] = 0.f;
   for (int qt = 0; qt < HW; qt += 32) {
     __syncthreads();
-    for (int e = tid; e < 32 * 32; e += NW * 64) { int r = e >> 5, c = e & 31; sq[r * LK + c] = c < D ? qb[(size_t)(qt + r) * D + c] : 0.f; }
-    for (int e = tid; e < 32 * C; e += NW * 64) { int r = e / C, c = e - r * C; sdo[r * LV + c] = d_o[((size_t)b * HW + qt + r) * C + c]; }
-    if (tid < 32) sls[tid] = lse[(size_t)b * HW + qt + tid];
-    else if (tid < 64) sls[tid] = delta[(size_t)b * HW + qt + tid - 32];
+    for (int e = tid; e < 32 * 32; e += NW * 64) { int r = e >> 5, c = e & 31; sq[r * LK + c] = (c < D && qt + r < HW) ? qb[(size_t)(qt + r) * D + c] : 0.f; }
+    for (int e = tid; e < 32 * C; e += NW * 64) { int r = e / C, c = e - r * C; sdo[r * LV + c] = qt + r < HW ? d_o[((size_t)b * HW + qt + r) * C + c] : 0.f; }
+    // queries past a ragged end: lse = +inf makes their probability exp(s - lse) exactly 0
+    if (tid < 32) sls[tid] = qt + tid < HW ? lse[(size_t)b * HW + qt + tid] : __builtin_inff();
+    else if (tid < 64) sls[tid] = qt + tid - 32 < HW ? delta[(size_t)b * HW + qt + tid - 32] : 0.f;
     __syncthreads();
     if (!wave_active) continue;
     f32x16 s, dp;
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_t(const float* __restric
 #pragma unroll
     for (int t = 0; t < 16; ++t) dka = __builtin_amdgcn_mfma_f32_32x32x2f32(sq[rho(t, h) * LK + l32], s[t], dka, 0, 0, 0);
   }
-  if (!wave_active) return;
+  if (!k_ok) return;
   float* ov = dv + ((size_t)b * HW + k0 + l32) * C;
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb)
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_t(const float* __restric
 
 // ---------------------------------------------------------------------------------------------
 static int attn_check(int b, int hw, int d, int c) {
-  VG_REQUIRE(b > 0 && hw > 0 && hw % 32 == 0, "attention: HW=%d must be a positive multiple of 32", hw);
+  VG_REQUIRE(b > 0 && hw > 0, "attention: HW=%d must be positive", hw);
   VG_REQUIRE(d > 0 && d <= 32 && d % 2 == 0, "attention: q/k width %d unsupported (even, <= 32)", d);
   VG_REQUIRE(c == 32 || c == 64 || c == 128 || c == 256, "attention: value width %d unsupported (32/64/128/256)", c);
   return VG_OK;

@@ -8,6 +8,7 @@ dtype (bf16 or f32); module boundaries convert from/to the reference's NCHW f32 
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from typing import Optional
 
 import torch
@@ -880,7 +881,7 @@ def _from_f32(t: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
 class AttentionFn(torch.autograd.Function):
     """out = gamma * softmax(q k^T) v + x on NHWC tensors [B,H,W,*] (q,k: [..,dqk_s], v,x: [..,cs]).
     bf16 mode: the products run on the bf16 MFMA straight from the bf16 tensors (vg_attn_*_bf16) where the shape is
-    covered; otherwise, and always in f32 mode, on the exact-f32 MFMA."""
+    covered; otherwise, and always in f32 mode (or with VG_ATTN_F32=1 in the environment), on the exact-f32 MFMA."""
 
     @staticmethod
     def forward(ctx, q, k, v, x, gamma):
@@ -889,7 +890,7 @@ class AttentionFn(torch.autograd.Function):
         dt = x.dtype
         b, hh, ww, cs = v.shape
         hw, d = hh * ww, q.shape[-1]
-        fast = dt == torch.bfloat16 and bool(lib.vg_attn_supported_bf16(hw, d, cs))
+        fast = dt == torch.bfloat16 and bool(lib.vg_attn_supported_bf16(hw, d, cs)) and not _os.environ.get("VG_ATTN_F32")
         xf = _to_f32(x)
         o = torch.empty(b, hh, ww, cs, dtype=torch.float32, device=q.device)
         lse = torch.empty(b * hw, dtype=torch.float32, device=q.device)
@@ -906,6 +907,7 @@ class AttentionFn(torch.autograd.Function):
         L.check(lib.vg_gamma_residual(o.data_ptr(), xf.data_ptr(), gam.data_ptr(), y.data_ptr(), y.numel(), L.stream()), "gamma_residual")
         ctx.save_for_backward(qf, kf, vf, o, lse, gam)
         ctx.dt, ctx.dims, ctx.fast = dt, (b, hw, d, cs), fast
+        ctx.in_dts = (q.dtype, k.dtype, v.dtype)
         return _from_f32(y, dt)
 
     @staticmethod
@@ -928,7 +930,8 @@ class AttentionFn(torch.autograd.Function):
         dgamma = torch.empty(1, dtype=torch.float32, device=o.device)
         L.check(lib.vg_scalar_finish(dgam.data_ptr(), 1.0, dgamma.data_ptr(), L.stream()), "dgamma")
         dt = ctx.dt
-        return _from_f32(dq, dt), _from_f32(dk, dt), _from_f32(dv, dt), _from_f32(gyf, dt) if dt != torch.float32 else gyf, dgamma
+        qd, kd, vd = ctx.in_dts
+        return _from_f32(dq, qd), _from_f32(dk, kd), _from_f32(dv, vd), _from_f32(gyf, dt) if dt != torch.float32 else gyf, dgamma
 
 
 def attention(q, k, v, x, gamma):
