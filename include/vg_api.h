@@ -213,6 +213,30 @@ int vg_gamma_residual_bwd(const float* gy, const float* o, const float* gamma, f
 /* elementwise storage cast bf16 <-> f32 (n % 8 == 0). */
 int vg_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 
+/* ---- VQ index entropy coder (vq_vae_gan/model.py:337-576) ---------------------------------------
+ * The on-disk format is the reference's: (bytes, shape, probs), bytes = ArithmeticEncoder.encode's output. */
+/* calculate_codebook_usage (model.py:540-554): probs[k] = histc(float(indices), bins=k, min=0, max=k-1) / sum.
+ * exact_bins == 0 reproduces torch.histc's float32 binning floor(x / (k-1) * k) (at k = 8192 it files index 8190
+ * under 8191); exact_bins != 0 counts index i in bin i.  counts_ws: k+1 ints of scratch.  n < 2^24. */
+int vg_codebook_usage(const int64_t* indices, int64_t n, int k, int exact_bins, int* counts_ws, float* probs, void* stream);
+/* The coder's table (model.py:369-380): probs == NULL: p = 1.0f/k; else p = probs / f32(sum probs) in float32; then
+ * cum[0] = 0, cum[i+1] = cum[i] + (double)p[i] in that order.  cum: k+1 doubles. */
+int vg_ac_table(const float* probs, int k, double* cum, void* stream);
+/* Bytes one stream can need at worst (32 bits per symbol + termination). */
+int64_t vg_ac_stream_capacity(int64_t symbols_per_stream);
+/* ArithmeticEncoder.encode (model.py:355-445), precision 32, for n_streams independent streams of
+ * symbols_per_stream indices each (the reference codes one stream per call: n_streams = 1), all with the table
+ * `cum`.  Stream i is written to out + i*cap_per_stream, its length to nbytes[i]; status[i]: 0 ok, 1 a symbol with
+ * probability 0 (the reference's loop never terminates on one), 2 capacity exceeded, 3 index outside [0,k),
+ * 4 coder state outside the supported range.  One wave per stream. */
+int vg_ac_encode(const int64_t* indices, int n_streams, int64_t symbols_per_stream, const double* cum, int k, uint8_t* out,
+                 int64_t cap_per_stream, int* nbytes, int* status, void* stream);
+/* Inverse of vg_ac_encode (bits past the end of a stream read as 0).  The reference's ArithmeticEncoder.decode
+ * (model.py:447-537) does not invert its own encode (it advances its bit pointer with the symbol counter, :491 and
+ * :530-532); this is the decoder of the format encode defines. */
+int vg_ac_decode(const uint8_t* data, const int* nbytes, int n_streams, int64_t cap_per_stream, int64_t symbols_per_stream,
+                 const double* cum, int k, int64_t* indices, int* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

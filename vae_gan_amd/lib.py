@@ -81,6 +81,11 @@ SIGNATURES = {
     "vg_gamma_residual_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
     "vg_cast": (_I, [_P, _P, _L, _I, _I, _P]),
     "vg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "vg_codebook_usage": (_I, [_P, _L, _I, _I, _P, _P, _P]),
+    "vg_ac_table": (_I, [_P, _I, _P, _P]),
+    "vg_ac_stream_capacity": (_L, [_L]),
+    "vg_ac_encode": (_I, [_P, _I, _L, _P, _I, _P, _L, _P, _P, _P]),
+    "vg_ac_decode": (_I, [_P, _P, _I, _L, _L, _P, _I, _P, _P, _P]),
 }
 
 
