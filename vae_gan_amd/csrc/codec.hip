@@ -27,18 +27,30 @@ __device__ inline double readlane_d(double v, int lane) {
 }
 
 // ---- histogram -----------------------------------------------------------------------------------------------
-__global__ void hist_kernel(const int64_t* __restrict__ idx, int64_t n, int k, int exact_bins, int* __restrict__ counts) {
-  const float fk = (float)k, fmax = (float)(k - 1);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = idx[i];
-    if (s < 0 || s > k - 1) continue;                       // histc ignores values outside [min, max]
-    int b;
-    if (exact_bins) b = (int)s;
-    else {                                                  // torch.histc: (int64)((x - min) / (max - min) * bins) in f32
-      b = (int)((float)s / fmax * fk);
-      if (b >= k) b = k - 1;
-    }
-    atomicAdd(counts + b, 1);
+__device__ inline int hist_bin(int64_t s, int k, int exact_bins) {
+  if (s < 0 || s > k - 1) return -1;                         // histc ignores values outside [min, max]
+  if (exact_bins) return (int)s;
+  const int b = (int)((float)s / (float)(k - 1) * (float)k);  // torch.histc: (int64)((x - min) / (max - min) * bins) in f32
+  return b >= k ? k - 1 : b;
+}
+// A trained codebook's usage is skewed (a few codes take most hits), so same-address global atomics serialise:
+// blocks count in LDS and flush one atomic per used bin (13.3 ms -> tens of us for 4 M indices at K = 512).
+template <bool LDS_BINS>
+__global__ __launch_bounds__(256) void hist_kernel(const int64_t* __restrict__ idx, int64_t n, int k, int exact_bins,
+                                                   int* __restrict__ counts) {
+  extern __shared__ int s_bins[];
+  if (LDS_BINS) {
+    for (int i = threadIdx.x; i < k; i += 256) s_bins[i] = 0;
+    __syncthreads();
+  }
+  for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int b = hist_bin(idx[i], k, exact_bins);
+    if (b >= 0) atomicAdd(LDS_BINS ? s_bins + b : counts + b, 1);
+  }
+  if (LDS_BINS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < k; i += 256)
+      if (s_bins[i]) atomicAdd(counts + i, s_bins[i]);
   }
 }
 __global__ void hist_total_kernel(const int* __restrict__ counts, int k, int* __restrict__ total) {
@@ -337,9 +349,10 @@ int vg_codebook_usage(const int64_t* indices, int64_t n, int k, int exact_bins, 
   VG_REQUIRE(n > 0 && n < (1 << 24), "codebook_usage: %lld indices (supported: 1 .. 2^24-1, where float32 counts are exact)", (long long)n);
   hipStream_t s = (hipStream_t)stream;
   VG_HIP(hipMemsetAsync(counts_ws, 0, sizeof(int) * ((size_t)k + 1), s));
-  const int64_t want = vg_ceil_div(n, 256);
-  const int blocks = (int)(want < 2048 ? want : 2048);
-  hist_kernel<<<blocks, 256, 0, s>>>(indices, n, k, exact_bins, counts_ws);
+  const int64_t want = vg_ceil_div(n, 256 * 16);             // >= 16 indices per thread before a block pays its flush
+  const int blocks = (int)(want < 1 ? 1 : (want < 1024 ? want : 1024));
+  if (k <= 16384) hist_kernel<true><<<blocks, 256, sizeof(int) * (size_t)k, s>>>(indices, n, k, exact_bins, counts_ws);
+  else hist_kernel<false><<<blocks, 256, 0, s>>>(indices, n, k, exact_bins, counts_ws);
   VG_LAUNCH_CHECK();
   hist_total_kernel<<<1, 256, 0, s>>>(counts_ws, k, counts_ws + k);   // histogram.sum(): out-of-range indices do not count
   VG_LAUNCH_CHECK();
