@@ -237,6 +237,26 @@ int vg_ac_encode(const int64_t* indices, int n_streams, int64_t symbols_per_stre
 int vg_ac_decode(const uint8_t* data, const int* nbytes, int n_streams, int64_t cap_per_stream, int64_t symbols_per_stream,
                  const double* cum, int k, int64_t* indices, int* status, void* stream);
 
+/* ---- input transform (beta_vae_gans/data.py:106-119) ---------------------------------------------
+ * One decoded RGB image (uint8, HWC, height*width*3 bytes on the device) and the draws of the reference's random
+ * transforms for it: RandomHorizontalFlip, RandomVerticalFlip (data.py:108-109), then RandomResizedCrop's box
+ * (i, j, h, w) in the coordinates of the flipped image (data.py:110).  Eval transform (data.py:116-119): no flips,
+ * crop = the whole image. */
+typedef struct {
+  const uint8_t* src;
+  int height, width;
+  int flip_h, flip_v;
+  int crop_i, crop_j, crop_h, crop_w;
+} vg_aug_item;
+/* Workspace bytes vg_augment_batch needs for these items (0 on invalid items: see vg_last_error). */
+size_t vg_augment_ws_bytes(const vg_aug_item* items, int n, int out_h, int out_w);
+/* out[n][3][out_h][out_w] f32 = ToTensor(resize(crop(flips(image)), (out_h, out_w), BILINEAR)) with Pillow's 8-bit ImagingResample
+ * arithmetic (antialiased triangle filter, 22-bit fixed-point coefficients, horizontal pass rounded to uint8, then
+ * vertical), bit for bit; a box of the output's size is the identity, i.e. plain ToTensor (data.py:146-148).
+ * `items` is a HOST array (validated on the host: boxes inside images, sizes); images,
+ * workspace and output are device memory. */
+int vg_augment_batch(const vg_aug_item* items, int n, int out_h, int out_w, void* ws, size_t ws_bytes, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

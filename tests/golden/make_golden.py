@@ -425,9 +425,42 @@ def g_vq_codec():
     save("vq_codec", **out)
 
 
+def g_augment():
+    """Input transform (beta_vae_gans/data.py:106-119): the pixel arithmetic belongs to Pillow (the reference resizes
+    PIL images through torchvision, which is not installed here).  Vectors made by PILLOW ITSELF: flips
+    (Image.transpose), crop (Image.crop), Image.resize((S, S), BILINEAR); ToTensor = uint8 / 255 is left to the test."""
+    from PIL import Image
+    import PIL
+    rng = np.random.default_rng(2024)
+    out = {"pillow_version": np.array([int(x) for x in PIL.__version__.split(".")[:2]])}
+    #        H    W   S  fh fv  (i, j, h, w) or None = whole image (eval transform)
+    cases = [(97, 131, 64, 0, 0, (5, 7, 83, 113)), (97, 131, 64, 1, 0, (5, 7, 83, 113)), (97, 131, 64, 0, 1, (0, 0, 97, 120)),
+             (97, 131, 64, 1, 1, (14, 18, 80, 90)), (200, 300, 96, 1, 1, (10, 20, 170, 255)), (40, 50, 64, 0, 1, (3, 2, 33, 45)),
+             (64, 64, 64, 1, 0, (0, 0, 64, 64)), (301, 77, 32, 0, 0, None), (128, 192, 64, 0, 0, None), (64, 90, 64, 1, 1, (0, 11, 64, 64)),
+             (90, 64, 64, 0, 0, (13, 0, 64, 64)), (33, 29, 96, 1, 0, (2, 3, 30, 25))]
+    for n, (H, W, S, fh, fv, box) in enumerate(cases):
+        if n % 2:
+            yy, xx = np.mgrid[0:H, 0:W]
+            img = np.stack([(np.sin(yy / 6.0) + 1) * 127.5, (np.cos(xx / 4.0) + 1) * 127.5, (yy * 3 + xx * 5) % 256], -1).astype(np.uint8)
+        else:
+            img = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        pil = Image.fromarray(img)
+        if fh:
+            pil = pil.transpose(Image.FLIP_LEFT_RIGHT)
+        if fv:
+            pil = pil.transpose(Image.FLIP_TOP_BOTTOM)
+        i, j, h, w = box if box else (0, 0, H, W)
+        res = pil.crop((j, i, j + w, i + h)).resize((S, S), Image.BILINEAR)
+        out[f"c{n}:img"] = img
+        out[f"c{n}:params"] = np.array([S, fh, fv, i, j, h, w])
+        out[f"c{n}:out"] = np.asarray(res)
+    out["n_cases"] = len(cases)
+    save("augment", **out)
+
+
 GROUPS = {"vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
           "vq_step": g_vq_step, "losses": g_losses, "beta_modules": g_beta_modules,
-          "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step, "vq_codec": g_vq_codec}
+          "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step, "vq_codec": g_vq_codec, "augment": g_augment}
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -33,6 +33,14 @@ _F = C.c_float
 _D = C.c_double
 _DP = C.POINTER(ConvDesc)
 
+
+class AugItem(C.Structure):
+    _fields_ = [("src", C.c_void_p)] + [(n, C.c_int) for n in
+                                         ("height", "width", "flip_h", "flip_v", "crop_i", "crop_j", "crop_h", "crop_w")]
+
+
+_AP = C.POINTER(AugItem)
+
 # name -> (restype, argtypes); must list every symbol declared in include/vg_api.h
 SIGNATURES = {
     "vg_last_error": (C.c_char_p, []),
@@ -81,6 +89,8 @@ SIGNATURES = {
     "vg_gamma_residual_bwd": (_I, [_P, _P, _P, _P, _P, _L, _P]),
     "vg_cast": (_I, [_P, _P, _L, _I, _I, _P]),
     "vg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P]),
+    "vg_augment_ws_bytes": (C.c_size_t, [_AP, _I, _I, _I]),
+    "vg_augment_batch": (_I, [_AP, _I, _I, _I, _P, C.c_size_t, _P, _P]),
     "vg_codebook_usage": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "vg_ac_table": (_I, [_P, _I, _P, _P]),
     "vg_ac_stream_capacity": (_L, [_L]),
