@@ -50,11 +50,27 @@ extern "C" int vg_bn_finalize(const double* stats, int c, int cpad, int64_t coun
   return VG_OK;
 }
 
+// PIECE consecutive per-channel coefficients starting at channel ch0 (zeros beyond c): two 16-byte loads when the
+// piece is whole and aligned, instead of PIECE dependent scalar loads per array at the head of every thread.
+template <int PIECE>
+__device__ __forceinline__ void load_coef(const float* __restrict__ a, int ch0, int c, float* out) {
+  if (ch0 + PIECE <= c && (((uintptr_t)(a + ch0)) & 15) == 0) {
+#pragma unroll
+    for (int q = 0; q < PIECE / 4; ++q) {
+      const f32x4 t = *(const f32x4*)(a + ch0 + 4 * q);
+      out[4 * q] = t[0]; out[4 * q + 1] = t[1]; out[4 * q + 2] = t[2]; out[4 * q + 3] = t[3];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < PIECE; ++e) out[e] = ch0 + e < c ? a[ch0 + e] : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Thread (rr, pc) owns one 16-byte channel piece `pc` for the rows rr, rr+rpb*grid, ...: its PIECE
 // scale/shift coefficients stay in registers, and a wave still touches 1 KiB of contiguous memory.
 template <typename T, bool HAS_RES>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+__global__ __launch_bounds__(256, 4) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                          int64_t rows, int ppr, int c, int act) {
   constexpr int PIECE = Elt<T>::PIECE;
@@ -62,18 +78,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
   if (rr >= rpb) return;
   float sc[PIECE], sh[PIECE];
-#pragma unroll
-  for (int e = 0; e < PIECE; ++e) {
-    const int ch = pc * PIECE + e;
-    sc[e] = ch < c ? scale[ch] : 0.f;
-    sh[e] = ch < c ? shift[ch] : 0.f;
-  }
+  load_coef<PIECE>(scale, pc * PIECE, c, sc);
+  load_coef<PIECE>(shift, pc * PIECE, c, sh);
   const size_t cs = (size_t)ppr * PIECE;
-  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
-    const size_t off = (size_t)r * cs + pc * PIECE;
-    Piece<T> v, rs, o;
-    v.v = *(const decltype(v.v)*)(x + off);
-    if (HAS_RES) rs.v = *(const decltype(rs.v)*)(res + off);
+  auto finish = [&](const Piece<T>& v, const Piece<T>& rs, size_t off) {
+    Piece<T> o;
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) {
       float f = v.get(e) * sc[e] + sh[e];
@@ -84,6 +93,30 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
       o.set(e, f);
     }
     *(decltype(o.v)*)(y + off) = o.v;
+  };
+  // U rows in flight per thread: all loads of a round are issued before the first use (memory-level parallelism)
+  constexpr int U = 4;
+  const int64_t stride = rpb;                            // a block walks its own contiguous chunk of rows
+  const int64_t chunk = (((rows + gridDim.x - 1) / gridDim.x + rpb * U - 1) / (rpb * U)) * (rpb * U);
+  const int64_t rend = min(rows, (int64_t)(blockIdx.x + 1) * chunk);
+  int64_t r = (int64_t)blockIdx.x * chunk + rr;
+  for (; r + (U - 1) * stride < rend; r += U * stride) {
+    Piece<T> v[U], rs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t off = (size_t)(r + u * stride) * cs + pc * PIECE;
+      v[u].v = *(const decltype(v[u].v)*)(x + off);
+      if (HAS_RES) rs[u].v = *(const decltype(rs[u].v)*)(res + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) finish(v[u], rs[u], (size_t)(r + u * stride) * cs + pc * PIECE);
+  }
+  for (; r < rend; r += stride) {
+    const size_t off = (size_t)r * cs + pc * PIECE;
+    Piece<T> v, rs;
+    v.v = *(const decltype(v.v)*)(x + off);
+    if (HAS_RES) rs.v = *(const decltype(rs.v)*)(res + off);
+    finish(v, rs, off);
   }
 }
 
@@ -109,7 +142,9 @@ extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const floa
   const int ppr = cs / piece;
   const int64_t np = rows;
   hipStream_t st = (hipStream_t)stream;
-  dim3 g(row_blocks(rows, 256 / ppr, 8)), b(256);
+  int nb_fwd = row_blocks(rows, 256 / ppr, 16);
+  if (nb_fwd > 4096) nb_fwd = 4096;
+  dim3 g(nb_fwd), b(256);
   if (dtype == VG_BF16) {
     if (res) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, scale, shift, np, ppr, c, act);
     else hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, scale, shift, np, ppr, c, act);
@@ -142,25 +177,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
   float a1[PIECE], a2[PIECE], mu[PIECE], is[PIECE], sc[PIECE], sh[PIECE];
 #pragma unroll
-  for (int e = 0; e < PIECE; ++e) {
-    a1[e] = 0.f; a2[e] = 0.f;
-    const int ch = pc * PIECE + e;
-    mu[e] = ch < c ? mean[ch] : 0.f;
-    is[e] = ch < c ? invstd[ch] : 0.f;
-    sc[e] = (XMASK && ch < c) ? scale[ch] : 0.f;
-    sh[e] = (XMASK && ch < c) ? shift[ch] : 0.f;
+  for (int e = 0; e < PIECE; ++e) { a1[e] = 0.f; a2[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f; }
+  load_coef<PIECE>(mean, pc * PIECE, c, mu);
+  load_coef<PIECE>(invstd, pc * PIECE, c, is);
+  if (XMASK) {
+    load_coef<PIECE>(scale, pc * PIECE, c, sc);
+    load_coef<PIECE>(shift, pc * PIECE, c, sh);
   }
   double d1[PIECE], d2[PIECE];
 #pragma unroll
   for (int e = 0; e < PIECE; ++e) { d1[e] = 0.0; d2[e] = 0.0; }
   if (rr < rpb) {
     int cnt = 0;
-    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
-      const size_t off = (size_t)r * cs + pc * PIECE;
-      Piece<T> g, o, v;
-      g.v = *(const decltype(g.v)*)(dout + off);
-      if (!XMASK) o.v = *(const decltype(o.v)*)(y + off);
-      v.v = *(const decltype(v.v)*)(x + off);
+    auto take = [&](const Piece<T>& g, const Piece<T>& o, const Piece<T>& v) {
 #pragma unroll
       for (int e = 0; e < PIECE; ++e) {
         float dz = g.get(e);
@@ -175,6 +204,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int e = 0; e < PIECE; ++e) { d1[e] += a1[e]; d2[e] += a2[e]; a1[e] = 0.f; a2[e] = 0.f; }
         cnt = 0;
       }
+    };
+    constexpr int U = 2;                                 // rows in flight per thread
+    const int64_t stride = rpb;                          // a block walks its own contiguous chunk of rows
+    const int64_t chunk = (((rows + gridDim.x - 1) / gridDim.x + rpb * U - 1) / (rpb * U)) * (rpb * U);
+    const int64_t rend = min(rows, (int64_t)(blockIdx.x + 1) * chunk);
+    int64_t r = (int64_t)blockIdx.x * chunk + rr;
+    for (; r + (U - 1) * stride < rend; r += U * stride) {
+      Piece<T> g[U], o[U], v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t off = (size_t)(r + u * stride) * cs + pc * PIECE;
+        g[u].v = *(const decltype(g[u].v)*)(dout + off);
+        if (!XMASK) o[u].v = *(const decltype(o[u].v)*)(y + off);
+        v[u].v = *(const decltype(v[u].v)*)(x + off);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) take(g[u], o[u], v[u]);
+    }
+    for (; r < rend; r += stride) {
+      const size_t off = (size_t)r * cs + pc * PIECE;
+      Piece<T> g, o, v;
+      g.v = *(const decltype(g.v)*)(dout + off);
+      if (!XMASK) o.v = *(const decltype(o.v)*)(y + off);
+      v.v = *(const decltype(v.v)*)(x + off);
+      take(g, o, v);
     }
   }
   // combine the rpb row-groups of this block through LDS, then one f64 atomic per channel per block
@@ -227,7 +281,8 @@ extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, 
 // ---------------------------------------------------------------------------------------------
 __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int cpad, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                   float* __restrict__ coef /* [3][cpad]: a = gamma*invstd, m1 = sum_dz/n, m2 = sum_dzxh/n */,
+                                   const float* __restrict__ mean,
+                                   float* __restrict__ coef /* [3][cpad]: dx = ca*dz - cb - cx*x */,
                                    float* dgamma, float* dbeta, int accumulate, float dgb_scale) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
@@ -236,9 +291,12 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
     s1 += sums[((size_t)r * 2 + 0) * cpad + ch];
     s2 += sums[((size_t)r * 2 + 1) * cpad + ch];
   }
-  coef[ch] = (gamma ? gamma[ch] : 1.f) * invstd[ch];
-  coef[cpad + ch] = (float)(s1 / count);
-  coef[2 * cpad + ch] = (float)(s2 / count);
+  // d = a*(dz - m1 - xh*m2), xh = (x-mu)*is  ==  a*dz - (a*m1 - a*m2*is*mu) - (a*m2*is)*x
+  const float a = (gamma ? gamma[ch] : 1.f) * invstd[ch], m1 = (float)(s1 / count), m2 = (float)(s2 / count);
+  const float cx = a * m2 * invstd[ch];
+  coef[ch] = a;
+  coef[cpad + ch] = a * m1 - cx * mean[ch];
+  coef[2 * cpad + ch] = cx;
   const float g2 = (float)(s2 * (double)dgb_scale), g1 = (float)(s1 * (double)dgb_scale);
   if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + g2 : g2;
   if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + g1 : g1;
@@ -260,26 +318,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   float acc[PIECE];
 #pragma unroll
   for (int e = 0; e < PIECE; ++e) acc[e] = 0.f;
-  // d = a*(dz - m1 - xh*m2), xh = (x-mu)*is  ==  a*dz - (a*m1 - a*m2*is*mu) - (a*m2*is)*x
-  float ca[PIECE], cb[PIECE], cx[PIECE], sc[PIECE], sh[PIECE];
+  float ca[PIECE], cb[PIECE], cx[PIECE], sc[PIECE], sh[PIECE];     // dx = ca*dz - cb - cx*x (bn_bwd_coef_kernel)
 #pragma unroll
-  for (int e = 0; e < PIECE; ++e) {
-    const int ch = pc * PIECE + e;
-    if (ch < c) {
-      const float a = coef[ch], m1 = coef[cpad + ch], m2 = coef[2 * cpad + ch], mu = mean[ch], is = invstd[ch];
-      ca[e] = a; cx[e] = a * m2 * is; cb[e] = a * m1 - cx[e] * mu;
-      sc[e] = XMASK ? scale[ch] : 0.f; sh[e] = XMASK ? shift[ch] : 0.f;
-    } else {
-      ca[e] = 0.f; cx[e] = 0.f; cb[e] = 0.f; sc[e] = 0.f; sh[e] = 0.f;
-    }
+  for (int e = 0; e < PIECE; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
+  load_coef<PIECE>(coef, pc * PIECE, c, ca);
+  load_coef<PIECE>(coef + cpad, pc * PIECE, c, cb);
+  load_coef<PIECE>(coef + 2 * cpad, pc * PIECE, c, cx);
+  if (XMASK) {
+    load_coef<PIECE>(scale, pc * PIECE, c, sc);
+    load_coef<PIECE>(shift, pc * PIECE, c, sh);
   }
   const size_t cs = (size_t)ppr * PIECE;
-  for (int64_t r = (int64_t)blockIdx.x * rpb + rr; rr < rpb && r < rows; r += (int64_t)gridDim.x * rpb) {
-    const size_t off = (size_t)r * cs + pc * PIECE;
-    Piece<T> g, o, v, rx, rd;
-    g.v = *(const decltype(g.v)*)(dout + off);
-    if (!XMASK) o.v = *(const decltype(o.v)*)(y + off);
-    v.v = *(const decltype(v.v)*)(x + off);
+  auto finish = [&](const Piece<T>& g, const Piece<T>& o, const Piece<T>& v, size_t off) {
+    Piece<T> rx, rd;
 #pragma unroll
     for (int e = 0; e < PIECE; ++e) {
       float dz = g.get(e);
@@ -292,6 +343,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     *(decltype(rx.v)*)(dx + off) = rx.v;
     if (HAS_DRES) *(decltype(rd.v)*)(dres + off) = rd.v;
+  };
+  if (rr < rpb) {
+    constexpr int U = 2;                                   // rows in flight per thread
+    const int64_t stride = rpb;                            // a block walks its own contiguous chunk of rows
+    const int64_t chunk = (((rows + gridDim.x - 1) / gridDim.x + rpb * U - 1) / (rpb * U)) * (rpb * U);
+    const int64_t rend = min(rows, (int64_t)(blockIdx.x + 1) * chunk);
+    int64_t r = (int64_t)blockIdx.x * chunk + rr;
+    for (; r + (U - 1) * stride < rend; r += U * stride) {
+      Piece<T> g[U], o[U], v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t off = (size_t)(r + u * stride) * cs + pc * PIECE;
+        g[u].v = *(const decltype(g[u].v)*)(dout + off);
+        if (!XMASK) o[u].v = *(const decltype(o[u].v)*)(y + off);
+        v[u].v = *(const decltype(v[u].v)*)(x + off);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) finish(g[u], o[u], v[u], (size_t)(r + u * stride) * cs + pc * PIECE);
+    }
+    for (; r < rend; r += stride) {
+      const size_t off = (size_t)r * cs + pc * PIECE;
+      Piece<T> g, o, v;
+      g.v = *(const decltype(g.v)*)(dout + off);
+      if (!XMASK) o.v = *(const decltype(o.v)*)(y + off);
+      v.v = *(const decltype(v.v)*)(x + off);
+      finish(g, o, v, off);
+    }
   }
   if (dxsum != nullptr) {     // block-uniform: per-channel sum of dx over this block's rows, one f32 atomic per channel
     const int width = ppr * PIECE;
@@ -322,12 +400,16 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   hipStream_t st = (hipStream_t)stream;
   // coefficient scratch lives right behind the f64 sums (caller allocates [REPLICAS*2*cpad] f64 + 3*cpad f32)
   float* coef = (float*)(sums + (size_t)VG_STATS_REPLICAS * 2 * cpad);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)(count > 0 ? count : rows), gamma, invstd, coef, dgamma, dbeta, accumulate, dgb_scale);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)(count > 0 ? count : rows), gamma, invstd, mean, coef, dgamma, dbeta, accumulate, dgb_scale);
   VG_LAUNCH_CHECK();
   const int ppr = cs / piece;
   const int64_t np = rows;
-  int nblocks = row_blocks(rows, 256 / ppr, 8);
-  if (dxsum != nullptr && nblocks > 1024) nblocks = 1024;      // every block ends with c same-address f32 atomics
+  int nblocks = row_blocks(rows, 256 / ppr, 16);               // >= 16 rows per thread: the coefficient preamble amortises
+  if (nblocks > 2048) nblocks = 2048;
+  if (dxsum != nullptr) {                                      // every block ends with c same-address f32 atomics
+    const int cap = 262144 / c < 256 ? 256 : 262144 / c;        // <= 256 K atomics per launch (c = 512: 56 -> 48 us)
+    if (nblocks > cap) nblocks = cap;
+  }
   dim3 g(nblocks), b(256);
 #define VG_BN_APPLY(T, DR, XM)                                                                                      \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DR, XM>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
