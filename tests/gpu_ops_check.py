@@ -113,6 +113,11 @@ CASES = [
     (1, 32, 32, 64, 256, 4, 1, 1),    # 4x4 stride-1 (discriminator tail), 31x31 output
     (1, 64, 64, 64, 128, 4, 2, 1),    # dgrad = 4 phases of 2x2 taps, 64-channel config with 3 halo buffers
     (1, 64, 64, 128, 64, 4, 2, 1),    # dgrad with 128 output channels
+    # forward of 4x4 stride-2 convs on the parity planes (igemm3s2: >= 24 output px wide)
+    (2, 48, 80, 64, 128, 4, 2, 1),    # ragged tiles in both directions (24 x 40 outputs)
+    (1, 64, 64, 3, 64, 4, 2, 1),      # thin input (discriminator head): one 64-byte chunk per plane
+    (1, 64, 128, 256, 512, 4, 2, 1),  # 256-channel config, 8 chunks per plane
+    (1, 52, 60, 32, 64, 4, 2, 1),     # 64-channel config, 30-px rows
 ]
 
 if __name__ == "__main__":

@@ -42,6 +42,7 @@ struct IgemmParams {
   // spatial-tile ("halo") kernel only
   int tilesX, tilesY, HH, HWd, nsh;
   int flip;               // igemm3: tap offsets descend (input gradients, transposed gathers)
+  int lgc;                // igemm3 stride-2 forward: log2 of the real 64-byte channel chunks per pixel
   int dbg;             // timing ablations only (wrong results): 1 = no in-loop DMA, 2 = no barrier/wait, 4 = no LDS fragment reads
   signed char dymin[VG_MAX_PHASES], dxmin[VG_MAX_PHASES];
   // tap offsets again, 4 bits per tap biased by 8: the kernels index them with scalar shifts.  (A dynamic
@@ -668,10 +669,19 @@ struct Igemm3Cfg {
   static constexpr bool FITS = LDS <= 160 * 1024 && (NSH == 2 || HRN <= 2 * NTAPS);
 };
 
-template <typename T, int MI, int NI, int WM, int WN, int R, int S>
-__global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
+// S2 = true: the 4x4 stride-2 pad-1 FORWARD gather, run as a 2x2-tap stride-1 gather over the four parity planes of
+// the input, X_ab[i][j] = x[2i-1+a][2j-1+b] (a virtual (OH+1) x (OW+1) image with 4C channels: plane-major chunks):
+//   y[i][j] = sum_{dr,ds in {0,1}} sum_{a,b,c} X_ab[i+dr][j+ds][c] * W[o][c][2dr+a][2ds+b].
+// Nothing is materialised: a halo piece of virtual chunk (plane, ic) is fetched from pixel (2i-1+a, 2j-1+b) (one
+// scalar addend per plane on top of the piece's offset for plane (0,0)), the weight tile of virtual tap (dr,ds) and
+// that chunk is tap (2dr+a, 2ds+b) of the ordinary packed forward weights, and pieces that leave the image in one
+// plane but not in another are fetched from a block of zeros for that plane.  The activations then travel L2 -> LDS
+// once per tile instead of once per tap (16x) as in the im2col-row kernel that ran these layers at 27 % MFMA busy.
+template <typename T, int MI, int NI, int WM, int WN, int R, int S, bool S2>
+__device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   typedef Igemm3Cfg<T, MI, NI, WM, WN, R, S> Cfg;
   static_assert(WM * WN == 8, "two groups of four waves");
+  static_assert(!S2 || (R == 2 && S == 2), "the stride-2 forward runs on the 2x2 tap grid");
   constexpr int NT = Cfg::NT, TW = Cfg::TW, TH = Cfg::TH, BM = Cfg::BM, BN = Cfg::BN;
   constexpr int EB = Cfg::EB, KC = Cfg::KC, PIECE = Cfg::PIECE;
   constexpr int NTAPS = Cfg::NTAPS, PF = Cfg::PF, NSB = Cfg::NSB, NPH = Cfg::NPH, KPP = Cfg::KPP;
@@ -718,6 +728,7 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
   // Pieces outside the image are zeroed here in every halo buffer and never written again.
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
   unsigned poff[HRN];       // byte offset of the piece in channel chunk 0, 0xFFFFFFFF = not fetched
+  unsigned pval[HRN];       // S2: bit (2a+b) = the piece is inside the image in parity plane (a,b); poff is then SIGNED, plane (0,0)
   const int iy_base = ty0 + dymin, ix_base = tx0 + dxmin;
 #pragma unroll
   for (int rd = 0; rd < HRN; ++rd) {
@@ -726,16 +737,37 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
     const int hy = pix / HS, hx = pix - hy * HS;
     const int iy = iy_base + hy, ix = ix_base + hx;
     unsigned o = 0xFFFFFFFFu;
-    if (hy < HH && hx < TW + S - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-      o = (unsigned)((((size_t)(img * p.H + iy) * p.W + ix) * p.Cs) * EB) + (((ps ^ (hx >> 2)) & 3) << 4);
-    poff[rd] = o;
-    if (o == 0xFFFFFFFFu) {
+    if constexpr (S2) {
+      const int row0 = 2 * iy - 1, col0 = 2 * ix - 1;
+      unsigned m = 0;
+      if (hy < HH && hx < TW + S - 1) {
 #pragma unroll
-      for (int b = 0; b < NSH; ++b) *(u32x4*)(smem + b * HBYTES + q * 16) = u32x4{0, 0, 0, 0};
+        for (int ab = 0; ab < 4; ++ab)
+          if ((unsigned)(row0 + (ab >> 1)) < (unsigned)p.H && (unsigned)(col0 + (ab & 1)) < (unsigned)p.W) m |= 1u << ab;
+      }
+      pval[rd] = m;
+      const long off = (((long)(img * p.H + row0) * p.W + col0) * p.Cs) * EB + (((ps ^ (hx >> 2)) & 3) << 4);
+      if (m) o = (unsigned)(int)off;
+      poff[rd] = o;
+      if (m == 0) {
+#pragma unroll
+        for (int b = 0; b < NSH; ++b) *(u32x4*)(smem + b * HBYTES + q * 16) = u32x4{0, 0, 0, 0};
+      }
+    } else {
+      pval[rd] = 0;
+      if (hy < HH && hx < TW + S - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        o = (unsigned)((((size_t)(img * p.H + iy) * p.W + ix) * p.Cs) * EB) + (((ps ^ (hx >> 2)) & 3) << 4);
+      poff[rd] = o;
+      if (o == 0xFFFFFFFFu) {
+#pragma unroll
+        for (int b = 0; b < NSH; ++b) *(u32x4*)(smem + b * HBYTES + q * 16) = u32x4{0, 0, 0, 0};
+      }
     }
   }
-  const int cchunks = p.C / KC;
-  const size_t ktot = (size_t)NTAPS * p.C;
+  const int cch = p.C / KC;                                 // real chunks per pixel
+  const int cchunks = S2 ? 4 * cch : cch;                   // S2: plane-major virtual chunks
+  const size_t ktot = (size_t)(S2 ? 16 : NTAPS) * p.C;      // S2: rows of the ordinary packed 4x4 forward weights
+  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
   const unsigned char* __restrict__ wg = (const unsigned char*)((const T*)p.w + ((size_t)phase * p.Npad + n0) * ktot);
   const int cbytes = p.C * EB;          // one tap of one weight row
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -768,14 +800,30 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
 
   // ---- DMA helpers; tap / round arguments are compile-time after unrolling
   auto dma_b = [&](int i, int itap, int icc, int slot) {
-    const unsigned char* src = wg + ((size_t)itap * cbytes + (size_t)icc * 64) + boff[i];
+    const unsigned char* src;
+    if constexpr (S2) {
+      const int plane = icc >> p.lgc, ic = icc & (cch - 1);
+      const int rs = (2 * (itap >> 1) + (plane >> 1)) * 4 + 2 * (itap & 1) + (plane & 1);
+      src = wg + ((size_t)rs * cbytes + (size_t)ic * 64) + boff[i];
+    } else {
+      src = wg + ((size_t)itap * cbytes + (size_t)icc * 64) + boff[i];
+    }
     unsigned char* dst = smem + SB_OFF + slot * BSTRIDE + (i * NT + wave * BLANES) * 16;
     if (BLANES == 64 || lane < BLANES) __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
   };
   auto dma_h = [&](int rd, int icc, int hboff) {
-    if (poff[rd] != 0xFFFFFFFFu)
-      __builtin_amdgcn_global_load_lds((gptr_t)(xg + (size_t)icc * 64 + poff[rd]),
-                                       (lds_ptr_t)(smem + hboff + (rd * NT + wave * 64) * 16), 16, 0, 0);
+    if constexpr (S2) {
+      if (pval[rd]) {
+        const int plane = icc >> p.lgc, ic = icc & (cch - 1);
+        const long add = (long)((plane >> 1) * p.W + (plane & 1)) * p.Cs * EB + (long)ic * 64;
+        const unsigned char* src = ((pval[rd] >> plane) & 1) ? xg + ((long)(int)poff[rd] + add) : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(smem + hboff + (rd * NT + wave * 64) * 16), 16, 0, 0);
+      }
+    } else {
+      if (poff[rd] != 0xFFFFFFFFu)
+        __builtin_amdgcn_global_load_lds((gptr_t)(xg + (size_t)icc * 64 + poff[rd]),
+                                         (lds_ptr_t)(smem + hboff + (rd * NT + wave * 64) * 16), 16, 0, 0);
+    }
   };
   // halo rounds of chunk icc that ride on the prefetch slot of tap itap
   auto halo_rounds = [&](int itap, int icc, int hboff) {
@@ -972,6 +1020,15 @@ __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
 #undef VG_STAMP
 
 template <typename T, int MI, int NI, int WM, int WN, int R, int S>
+__global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
+  igemm3_body<T, MI, NI, WM, WN, R, S, false>(p);
+}
+template <typename T, int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(512) void igemm3s2_kernel(const IgemmParams p) {
+  igemm3_body<T, MI, NI, WM, WN, 2, 2, true>(p);
+}
+
+template <typename T, int MI, int NI, int WM, int WN, int R, int S>
 static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
   typedef Igemm3Cfg<T, MI, NI, WM, WN, R, S> Cfg;
   *handled = false;
@@ -1021,6 +1078,56 @@ static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
   return VG_OK;
 }
 
+// 4x4 stride-2 pad-1 forward on the parity planes (igemm3_body<..., S2 = true>)
+static bool g_igemm3_s2 = true;
+template <typename T, int MI, int NI, int WM, int WN>
+static int launch_igemm3s2(const IgemmParams& p0, hipStream_t st, bool* handled) {
+  typedef Igemm3Cfg<T, MI, NI, WM, WN, 2, 2> Cfg;
+  *handled = false;
+  if constexpr (Cfg::FITS) {
+    IgemmParams p = p0;
+    const int cch = p.C / Cfg::KC;
+    if (cch < 1 || (cch & (cch - 1)) != 0) return VG_OK;                        // power-of-two chunk count (plane = chunk >> lgc)
+    if ((size_t)p.N * p.H * p.W * p.Cs * Cfg::EB >= ((size_t)1 << 31)) return VG_OK;   // signed 32-bit piece offsets
+    p.lgc = 0;
+    while ((1 << p.lgc) < cch) ++p.lgc;
+    p.ntaps = 4;
+    for (int t = 0; t < 4; ++t) { p.dy[0][t] = (signed char)(t >> 1); p.dx[0][t] = (signed char)(t & 1); }
+    p.dymin[0] = 0; p.dxmin[0] = 0;
+    p.flip = 0;
+    p.dbg = g_dbg;
+    p.tilesX = (int)vg_ceil_div(p.OWl, Cfg::TW);
+    p.tilesY = (int)vg_ceil_div(p.OHl, Cfg::TH);
+    p.mtiles = p.N * p.tilesX * p.tilesY;
+    p.ntiles = p.Npad / Cfg::BN;
+    auto kern = igemm3s2_kernel<T, MI, NI, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    pack_taps(p);
+    snprintf(g_last_kernel, sizeof g_last_kernel, "igemm3s2<%s,%d,%d,%d,%d>", tname<T>(), MI, NI, WM, WN);
+    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, 1), dim3(Cfg::NT), Cfg::LDS, st, p);
+    VG_LAUNCH_CHECK();
+    *handled = true;
+  }
+  return VG_OK;
+}
+template <typename T> static int dispatch_igemm3s2(const IgemmParams& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if (!g_igemm3_s2 || p.ntaps != 16 || p.nphases != 1 || (p.H & 1) || (p.W & 1) || p.OHl != p.H / 2 || p.OWl != p.W / 2) return VG_OK;
+  for (int t = 0; t < 16; ++t)
+    if (p.dy[0][t] != t / 4 - 1 || p.dx[0][t] != t % 4 - 1) return VG_OK;      // pad 1, row-major taps
+  if (p.Npad % 256 == 0) return launch_igemm3s2<T, 4, 2, 2, 4>(p, st, handled);
+  if (p.Npad == 128) {
+    if constexpr (Igemm3Cfg<T, 4, 2, 4, 2, 2, 2>::FITS) return launch_igemm3s2<T, 4, 2, 4, 2>(p, st, handled);
+    else return launch_igemm3s2<T, 2, 2, 4, 2>(p, st, handled);
+  }
+  if (p.Npad == 64) return launch_igemm3s2<T, 2, 2, 8, 1>(p, st, handled);
+  return VG_OK;
+}
+
 static int g_conv_kernel = 3;
 template <typename T, int R, int S> static int dispatch_igemm3_rs(const IgemmParams& p, hipStream_t st, bool* handled) {
   if (p.Npad % 256 == 0) return launch_igemm3<T, 4, 2, 2, 4, R, S>(p, st, handled);   // 8x32 px x 256 ch
@@ -1041,7 +1148,9 @@ template <typename T, int R, int S> static int dispatch_igemm3_rs(const IgemmPar
 template <typename T> static int dispatch_igemm3(const IgemmParams& p, hipStream_t st, bool* handled) {
   *handled = false;
   if constexpr (sizeof(T) == 2) {
-    if (g_conv_kernel < 3 || p.ksplit > 1 || p.in_s != 1 || p.OWl < 24) return VG_OK;
+    if (g_conv_kernel < 3 || p.ksplit > 1 || p.OWl < 24) return VG_OK;
+    if (p.in_s == 2) return dispatch_igemm3s2<T>(p, st, handled);
+    if (p.in_s != 1) return VG_OK;
     if (p.ntaps == 9) return dispatch_igemm3_rs<T, 3, 3>(p, st, handled);
     if (p.ntaps == 16) return dispatch_igemm3_rs<T, 4, 4>(p, st, handled);
     if (p.ntaps == 4) return dispatch_igemm3_rs<T, 2, 2>(p, st, handled);
@@ -1051,7 +1160,8 @@ template <typename T> static int dispatch_igemm3(const IgemmParams& p, hipStream
 
 static bool g_use_igemm2 = true;
 extern "C" void vg_set_conv_kernel(int version) {
-  g_conv_kernel = version & 0xff;
+  g_conv_kernel = version & 0x0f;                 // bit 4 (16): stride-2 forward stays on the im2col-row kernel
+  g_igemm3_s2 = !(version & 0x10);
   g_use_igemm2 = g_conv_kernel != 1;
   g_dbg = version >> 8;
 }
