@@ -79,7 +79,9 @@ int vg_conv_fwd_splitk(const vg_conv_desc* d, const void* x, const void* w_packe
 int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
                   double* stats, int act, int accumulate, void* stream);
 /* dW[O][I][R][S] (f32, OIHW) = sum over pixels of dy ⊗ im2col(x).  `ws` is f32 scratch of
- * vg_conv_wgrad_ws_bytes(d) bytes.  Serves both Conv2d.weight.grad and ConvTranspose2d.weight.grad
+ * vg_conv_wgrad_ws_bytes(d) bytes (one packed image of dW for the per-tap kernel; up to ~75 MB for the spatial-tile
+ * kernels, which write one partial image per tile group with plain stores and sum them in a fixed order: no
+ * atomics, bit-reproducible).  Serves both Conv2d.weight.grad and ConvTranspose2d.weight.grad
  * (roles of x / dy swapped by the caller).  accumulate != 0: dW += (the gradient goes straight into a
  * parameter's .grad, which the training step zeroed: a parameter used twice per backward sums up). */
 size_t vg_conv_wgrad_ws_bytes(const vg_conv_desc* d);

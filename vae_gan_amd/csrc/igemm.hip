@@ -1366,6 +1366,7 @@ struct WgradParams {
   signed char dy_[VG_MAX_TAPS];
   signed char dx_[VG_MAX_TAPS];
   int dbg;              // timing ablations only (VG_ABLATE build): 16 = one B fragment for all taps, 32 = no in-loop DMA, 64 = no barrier
+  size_t part_elems;    // spatial-tile kernels: dw is [groups * KS][part_elems] partial images, written with plain stores
 };
 
 // 64-byte-segment swizzle for [pixel][channel] tiles read through ds_read_b64_tr_b16 (bf16 only)
@@ -1593,6 +1594,13 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t st) {
 // in registers (144 accumulators) over its share of the tile rows; the slab is added to the f32
 // workspace with atomics once, at the end.  One barrier per tile, counted vmcnt.
 // =============================================================================================
+// tile groups per slab pair: one block per CU (LDS-limited), at least; never more groups than tiles
+static int wg3_groups(int pairs, int n, int oh, int ow, int th, int tw) {
+  const int ntiles = n * (int)vg_ceil_div(oh, th) * (int)vg_ceil_div(ow, tw);
+  int G = (int)vg_ceil_div(256, pairs);
+  return G > ntiles ? ntiles : G;
+}
+
 template <int NOB, int NCB, int KS>
 struct Wg3Cfg {
   static constexpr int TH = 4, TW = 32, R = 3, S = 3, NTAPS = 9;
@@ -1748,17 +1756,48 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   }
 
   // acc[tap][r]: row (o) = (r&3) + 8*(r>>2) + 4*h, column (c) = l32
+  // Every (tile group, row split) pair owns one partial image of dW and writes it with plain stores; the unpack kernel
+  // sums the partials in a fixed order.  (One pass of f32 atomics into a single image cost 50-100 us per launch, a
+  // fifth of the kernel, and made the gradient depend on the order the blocks finished in.)
+  // With two row splits the second wave of each (o, c) block hands its accumulators to the first through the (now
+  // idle) stage buffers, five taps at a time, so a block writes ONE partial image (half the partial traffic).
+  if constexpr (KS == 2) {
+    static_assert(Cfg::LDS >= 4 * 5 * 16 * 64 * 4, "exchange buffer");
+    float* xch = (float*)smem + (size_t)(wave / KS) * (5 * 16 * 64) + lane;
+    __syncthreads();                                   // every wave is done with the stage buffers
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      constexpr int T0[2] = {0, 5}, T1[2] = {5, NTAPS};
+      if (ks == 1) {
+#pragma unroll
+        for (int tap = T0[half]; tap < T1[half]; ++tap)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xch[((tap - T0[half]) * 16 + r) * 64] = acc[tap][r];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int tap = T0[half]; tap < T1[half]; ++tap)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tap][r] += xch[((tap - T0[half]) * 16 + r) * 64];
+      }
+      __syncthreads();
+    }
+    if (ks != 0) return;
+  }
   const size_t rowstride = (size_t)NTAPS * p.Cpad;
+  float* __restrict__ part = p.dw + (size_t)(KS == 2 ? g : g * KS + ks) * p.part_elems;
   const int c = c0 + cb * 32 + l32;
-  if (c < p.Cpad) {
+  if (c < p.Cpad && !VG_DBG(128)) {
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (o < p.Opad) unsafeAtomicAdd(&p.dw[(size_t)o * rowstride + (size_t)tap * p.Cpad + c], acc[tap][r]);
+        if (o < p.Opad) part[(size_t)o * rowstride + (size_t)tap * p.Cpad + c] = acc[tap][r];
       }
   }
+  if (VG_DBG(128) && acc[0][0] == 123.f) p.dw[0] = acc[1][1] + acc[8][15];    // keep the accumulators alive
 }
 
 template <int NOB, int NCB, int KS>
@@ -1769,9 +1808,7 @@ static int launch_wgrad3(const WgradParams& p0, hipStream_t st) {
   p.otiles = (int)vg_ceil_div(p.Opad, Cfg::BO);
   p.ctiles = (int)vg_ceil_div(p.Cpad, Cfg::BC);
   const int pairs = p.otiles * p.ctiles;
-  const int ntiles = p.N * (int)vg_ceil_div(p.OH, Cfg::TH) * (int)vg_ceil_div(p.OW, Cfg::TW);
-  int G = (int)vg_ceil_div(256, pairs);                      // one block per CU (LDS-limited), at least
-  if (G > ntiles) G = ntiles;
+  const int G = wg3_groups(pairs, p.N, p.OH, p.OW, Cfg::TH, Cfg::TW);
   auto kern = wgrad3_kernel<NOB, NCB, KS>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1941,6 +1978,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   }
 
   const size_t rowstride = (size_t)16 * p.Cpad;
+  float* __restrict__ part = p.dw + (size_t)(g * KS + ks) * p.part_elems;      // see wgrad3_kernel
   const int c = c0 + cb * 32 + l32;
   if (c < p.Cpad) {
 #pragma unroll
@@ -1949,7 +1987,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (o < p.Opad) unsafeAtomicAdd(&p.dw[(size_t)o * rowstride + (size_t)tap * p.Cpad + c], acc[lt][r]);
+        if (o < p.Opad) part[(size_t)o * rowstride + (size_t)tap * p.Cpad + c] = acc[lt][r];
       }
     }
   }
@@ -1962,9 +2000,7 @@ static int launch_wgrad3s2(const WgradParams& p0, hipStream_t st) {
   p.otiles = (int)vg_ceil_div(p.Opad, Cfg::BO);
   p.ctiles = (int)vg_ceil_div(p.Cpad, Cfg::BC);
   const int pairs = p.otiles * p.ctiles;
-  const int ntiles = p.N * (int)vg_ceil_div(p.OH, Cfg::TH) * (int)vg_ceil_div(p.OW, Cfg::TW);
-  int G = (int)vg_ceil_div(256, pairs);
-  if (G > ntiles) G = ntiles;
+  const int G = wg3_groups(pairs, p.N, p.OH, p.OW, Cfg::TH, Cfg::TW);
   auto kern = wgrad3s2_kernel<NOB, NCB, KS>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1979,22 +2015,42 @@ static int launch_wgrad3s2(const WgradParams& p0, hipStream_t st) {
 static int g_wgrad_kernel = 3;
 extern "C" void vg_set_wgrad_kernel(int version) { g_wgrad_kernel = version; }
 
-// returns true when the spatial-tile kernel took the launch
-static bool dispatch_wgrad3(const WgradParams& p, int R, int S, int dtype, hipStream_t st, int* rc) {
-  if (g_wgrad_kernel < 3 || dtype != VG_BF16) return false;
+// Which spatial-tile configuration takes a weight gradient (0 = none: the per-tap kernel), and how many partial images
+// of dW it writes (tile groups x row splits).  Shared by the workspace query and the launch.
+struct Wg3Plan { int kind, nob, ncb, ks, parts; };     // kind 1: 3x3 stride 1, 2: 4x4 stride 2
+static Wg3Plan wg3_plan(const WgradParams& p, int R, int S, int dtype) {
+  Wg3Plan q = {0, 0, 0, 0, 1};
+  if (g_wgrad_kernel < 3 || dtype != VG_BF16) return q;
   if ((size_t)p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31) || (size_t)p.OH * p.OW * p.Os * 2 >= ((size_t)1 << 31))
-    return false;                                            // piece offsets are 32-bit inside one image
+    return q;                                                // piece offsets are 32-bit inside one image
+  int th, tw;
   if (p.in_s == 2 && R == 4 && S == 4 && p.dy_[0] == -1 && p.dx_[0] == -1 && p.OW >= 8) {
-    if (p.Opad >= 128) *rc = launch_wgrad3s2<4, 1, 1>(p, st);
-    else if (p.Opad > 32) *rc = launch_wgrad3s2<2, 1, 2>(p, st);
-    else *rc = launch_wgrad3s2<1, 1, 4>(p, st);
-    return true;
+    q.kind = 2; th = 4; tw = 16;
+    if (p.Opad >= 128) { q.nob = 4; q.ncb = 1; q.ks = 1; }
+    else if (p.Opad > 32) { q.nob = 2; q.ncb = 1; q.ks = 2; }
+    else { q.nob = 1; q.ncb = 1; q.ks = 4; }
+  } else if (p.in_s == 1 && R == 3 && S == 3 && p.OW >= 24) {
+    q.kind = 1; th = 4; tw = 32;
+    if (p.Opad <= 32) { q.nob = 1; q.ncb = 2; q.ks = 4; }
+    else if (p.Cpad <= 32) { q.nob = 2; q.ncb = 1; q.ks = 4; }
+    else { q.nob = 2; q.ncb = 2; q.ks = 2; }
+  } else {
+    return q;
   }
-  if (p.in_s != 1 || R != 3 || S != 3 || p.OW < 24) return false;
-  if (p.Opad <= 32) *rc = launch_wgrad3<1, 2, 4>(p, st);
-  else if (p.Cpad <= 32) *rc = launch_wgrad3<2, 1, 4>(p, st);
-  else *rc = launch_wgrad3<2, 2, 2>(p, st);
-  return true;
+  const int pairs = (int)vg_ceil_div(p.Opad, 32 * q.nob) * (int)vg_ceil_div(p.Cpad, 32 * q.ncb);
+  // row splits: the 64x64-slab 3x3 kernel combines its two inside the block, the others write one image per split
+  q.parts = wg3_groups(pairs, p.N, p.OH, p.OW, th, tw) * (q.kind == 1 && q.ks == 2 ? 1 : q.ks);
+  return q;
+}
+static int dispatch_wgrad3(const WgradParams& p, const Wg3Plan& q, hipStream_t st) {
+  if (q.kind == 2) {
+    if (q.nob == 4) return launch_wgrad3s2<4, 1, 1>(p, st);
+    if (q.nob == 2) return launch_wgrad3s2<2, 1, 2>(p, st);
+    return launch_wgrad3s2<1, 1, 4>(p, st);
+  }
+  if (q.nob == 1) return launch_wgrad3<1, 2, 4>(p, st);
+  if (q.ncb == 1) return launch_wgrad3<2, 1, 4>(p, st);
+  return launch_wgrad3<2, 2, 2>(p, st);
 }
 
 template <typename T> static int dispatch_wgrad(const WgradParams& p, hipStream_t st) {
@@ -2010,24 +2066,54 @@ template <typename T> static int dispatch_wgrad(const WgradParams& p, hipStream_
   return launch_wgrad<T, 2, 2, 1, 1, 4>(p, st);                        // 64 x 64
 }
 
-__global__ void wgrad_unpack_kernel(const float* __restrict__ packed, float* __restrict__ dw, int O, int I, int RS,
-                                    int Cpad, int accumulate) {
-  // dw[o][i][rs] = packed[o][rs][i]
+// dw[o][i][rs] (+)= sum over the partial images of packed[part][o][rs][i], in a fixed order: a block takes 64
+// consecutive (o, rs, i) items (i fastest: coalesced reads), its four waves split the partials, LDS combines them.
+__global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restrict__ packed, int parts, size_t part_elems,
+                                                           float* __restrict__ dw, int O, int I, int RS, int Cpad,
+                                                           int accumulate) {
+  __shared__ float red[4][64];
   const long total = (long)O * I * RS;
-  for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    int rs = (int)(t % RS);
-    long oi = t / RS;
-    int i = (int)(oi % I);
-    int o = (int)(oi / I);
-    const float v = packed[((size_t)o * RS + rs) * Cpad + i];
-    dw[t] = accumulate ? dw[t] + v : v;
+  const int e = threadIdx.x & 63, gy = threadIdx.x >> 6;
+  const long t = blockIdx.x * 64L + e;
+  float v = 0.f;
+  long dst = 0;
+  if (t < total) {
+    const int i = (int)(t % I);
+    const long ors = t / I;
+    const int rs = (int)(ors % RS), o = (int)(ors / RS);
+    const float* src = packed + (size_t)ors * Cpad + i;
+    for (int g = gy; g < parts; g += 4) v += src[(size_t)g * part_elems];
+    dst = ((long)o * I + i) * RS + rs;
   }
+  red[gy][e] = v;
+  __syncthreads();
+  if (gy == 0 && t < total) {
+    const float sum = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    dw[dst] = accumulate ? dw[dst] + sum : sum;
+  }
+}
+
+static size_t wgrad_packed_elems(const vg_conv_desc* d) {
+  int opad = (int)vg_ceil_div(d->co, 32) * 32;
+  return (size_t)opad * d->r * d->s * cpad_of(d->ci, d->dtype);
+}
+static void wgrad_fill_params(const vg_conv_desc* d, WgradParams& p) {
+  memset(&p, 0, sizeof(p));
+  p.N = d->n; p.H = d->h; p.W = d->w; p.Cpad = cpad_of(d->ci, d->dtype); p.Cs = d->xcs;
+  p.OH = d->oh; p.OW = d->ow; p.Opad = (int)vg_ceil_div(d->co, 32) * 32; p.Os = d->ycs;
+  if (p.Opad > p.Os) p.Opad = p.Os;   // f32 strides are multiples of 16: never read past the row
+  p.in_s = d->stride; p.ntaps = d->r * d->s;
+  p.M = d->n * d->oh * d->ow;
+  for (int r = 0; r < d->r; ++r)
+    for (int s = 0; s < d->s; ++s) { p.dy_[r * d->s + s] = (signed char)(r - d->pad); p.dx_[r * d->s + s] = (signed char)(s - d->pad); }
 }
 
 extern "C" size_t vg_conv_wgrad_ws_bytes(const vg_conv_desc* d) {
   if (!d) return 0;
-  int opad = (int)vg_ceil_div(d->co, 32) * 32;
-  return (size_t)opad * d->r * d->s * cpad_of(d->ci, d->dtype) * sizeof(float);
+  WgradParams p;
+  wgrad_fill_params(d, p);
+  const Wg3Plan q = wg3_plan(p, d->r, d->s, d->dtype);
+  return wgrad_packed_elems(d) * sizeof(float) * (size_t)q.parts;
 }
 
 extern "C" int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws,
@@ -2037,24 +2123,20 @@ extern "C" int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* d
   VG_REQUIRE(x && dy && dw_oihw && ws, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
   WgradParams p;
-  memset(&p, 0, sizeof(p));
+  wgrad_fill_params(d, p);
   p.x = x; p.dy = dy; p.dw = (float*)ws;
-  p.N = d->n; p.H = d->h; p.W = d->w; p.Cpad = cpad_of(d->ci, d->dtype); p.Cs = d->xcs;
-  p.OH = d->oh; p.OW = d->ow; p.Opad = (int)vg_ceil_div(d->co, 32) * 32; p.Os = d->ycs;
-  if (p.Opad > p.Os) p.Opad = p.Os;   // f32 strides are multiples of 16: never read past the row
-  p.in_s = d->stride; p.ntaps = d->r * d->s;
-  p.M = d->n * d->oh * d->ow;
-  for (int r = 0; r < d->r; ++r)
-    for (int s = 0; s < d->s; ++s) { p.dy_[r * d->s + s] = (signed char)(r - d->pad); p.dx_[r * d->s + s] = (signed char)(s - d->pad); }
-  VG_HIP(hipMemsetAsync(ws, 0, vg_conv_wgrad_ws_bytes(d), st));
-  if (!dispatch_wgrad3(p, d->r, d->s, d->dtype, st, &rc))
+  p.part_elems = wgrad_packed_elems(d);
+  const Wg3Plan q = wg3_plan(p, d->r, d->s, d->dtype);
+  if (q.kind) {
+    rc = dispatch_wgrad3(p, q, st);                          // plain stores into q.parts partial images: nothing to clear
+  } else {
+    VG_HIP(hipMemsetAsync(ws, 0, p.part_elems * sizeof(float), st));
     rc = d->dtype == VG_BF16 ? dispatch_wgrad<bf16_t>(p, st) : dispatch_wgrad<float>(p, st);
+  }
   if (rc) return rc;
   const long total = (long)d->co * d->ci * d->r * d->s;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw_oihw, d->co, d->ci,
-                     d->r * d->s, p.Cpad, accumulate);
+  hipLaunchKernelGGL(wgrad_unpack_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, (const float*)ws, q.parts,
+                     p.part_elems, dw_oihw, d->co, d->ci, d->r * d->s, p.Cpad, accumulate);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
