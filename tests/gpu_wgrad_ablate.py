@@ -13,7 +13,7 @@ def run(n, h, w, ci, co, k, stride, pad, iters=5):
     dw = torch.empty(co, ci, k, k, device="cuda")
     flops = 2.0 * n * d.oh * d.ow * co * ci * k * k
     res = []
-    for bits, name in ((0, "full"), (16, "oneB"), (32, "noDMA"), (64, "nobarrier"), (16 | 32, "oneB+noDMA"), (16 | 32 | 64, "mfma+A only"), (128, "no atomics"), (16 | 32 | 64 | 128, "mfma+A, no atomics")):
+    for bits, name in ((0, "full"), (16, "oneB"), (32, "noDMA"), (64, "nobarrier"), (16 | 32, "oneB+noDMA"), (16 | 32 | 64, "mfma+A only"), (128, "no stores"), (16 | 32 | 64 | 128, "mfma+A, no stores")):
         lib.vg_set_conv_kernel(3 | (bits << 8))
         fn = lambda: lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, L.stream())
         fn(); torch.cuda.synchronize()

@@ -1745,11 +1745,12 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
         const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
       }
-      // prefetch of tile t+2G, spread over the k steps
+      // prefetch of tile t+2G, all of it at the first k step: the stream is latency-bound, and the earlier the pieces
+      // are in flight the better (spread over the k steps: 0.484 ms, all at once: 0.407 ms on 64->64@256^2)
       if (more && !VG_DBG(32)) {
 #pragma unroll
         for (int r = 0; r < PR; ++r)
-          if (r * KSTEPS / PR == kstep) issue_piece(r, nimg, nty0, ntx0, nstage);
+          if (kstep == 0) issue_piece(r, nimg, nty0, ntx0, nstage);
       }
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
@@ -1971,7 +1972,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
       if (more) {
 #pragma unroll
         for (int r = 0; r < PR; ++r)
-          if (r * ROWS / PR == j) issue_piece(r, nimg, nty0, ntx0, nstage);
+          if (j == 0) issue_piece(r, nimg, nty0, ntx0, nstage);
       }
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
