@@ -1730,6 +1730,12 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
     const int nstage = stage + 2 >= NST ? stage + 2 - NST : stage + 2;
     const unsigned char* sA = smem + stage * STAGE + abase;
     const unsigned char* sB = smem + stage * STAGE + bbase;
+    // prefetch of tile t+2G, all of it before the tile's own work: the stream is latency-bound, and the earlier the
+    // pieces are in flight the better (spread over the k steps: 0.484 ms, all at once: 0.407 ms on 64->64@256^2)
+    if (more && !VG_DBG(32)) {
+#pragma unroll
+      for (int r = 0; r < PR; ++r) issue_piece(r, nimg, nty0, ntx0, nstage);
+    }
 #pragma unroll
     for (int kstep = 0; kstep < KSTEPS; ++kstep) {
       const int j = kstep >> 1, kx = kstep & 1;
@@ -1744,13 +1750,6 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
         bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64));
         const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
-      }
-      // prefetch of tile t+2G, all of it at the first k step: the stream is latency-bound, and the earlier the pieces
-      // are in flight the better (spread over the k steps: 0.484 ms, all at once: 0.407 ms on 64->64@256^2)
-      if (more && !VG_DBG(32)) {
-#pragma unroll
-        for (int r = 0; r < PR; ++r)
-          if (kstep == 0) issue_piece(r, nimg, nty0, ntx0, nstage);
       }
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
