@@ -259,11 +259,75 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
   if (threadIdx.x == 0 && sse != nullptr) unsafeAtomicAdd(sse, red[0] + red[1] + red[2] + red[3]);
 }
 
+// The same with the EMA statistics privatised in LDS (k*d + k floats <= 144 KB): the rows of a batch pile onto few
+// codes (a fresh codebook: nearly all onto a handful), so global f32 atomics on esum[code][:] serialise (230 us for
+// 65,536 x 64 at K = 512).  A block of 1024 threads accumulates its rows with LDS atomics and flushes the non-zero
+// entries once.
+__global__ __launch_bounds__(1024) void vq_gather_lds_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                             const int64_t* __restrict__ idx, int64_t rows, int K, int D,
+                                                             float* __restrict__ zq, double* __restrict__ sse,
+                                                             float* __restrict__ counts, float* __restrict__ esum) {
+  extern __shared__ float s_acc[];             // [K*D] sums, [K] counts
+  float* s_cnt = s_acc + (size_t)K * D;
+  const int total = K * D + K;
+  for (int i = threadIdx.x; i < total; i += 1024) s_acc[i] = 0.f;
+  __syncthreads();
+  const int tpr = D / 4;
+  const int rpb = 1024 / tpr;
+  const int c4 = threadIdx.x % tpr, rr = threadIdx.x / tpr;
+  float local = 0.f;
+  if (rr < rpb) {
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+      int code = (int)idx[r];
+      if (code < 0) code = 0;
+      if (code >= K) code = K - 1;
+      const f32x4 zv = *(const f32x4*)(z + (size_t)r * D + c4 * 4);
+      const f32x4 qv = *(const f32x4*)(cb + (size_t)code * D + c4 * 4);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float diff = qv[e] - zv[e];
+        o[e] = zv[e] + diff;
+        local += diff * diff;
+      }
+      *(f32x4*)(zq + (size_t)r * D + c4 * 4) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&s_acc[(size_t)code * D + c4 * 4 + e], zv[e]);
+      if (c4 == 0) atomicAdd(&s_cnt[code], 1.0f);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * D; i += 1024)
+    if (s_acc[i] != 0.f) unsafeAtomicAdd(&esum[i], s_acc[i]);
+  for (int i = threadIdx.x; i < K; i += 1024)
+    if (s_cnt[i] != 0.f) unsafeAtomicAdd(&counts[i], s_cnt[i]);
+  __shared__ double red[16];
+  double w = wave_sum_d((double)local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0 && sse != nullptr) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    unsafeAtomicAdd(sse, t);
+  }
+}
+
 extern "C" int vg_vq_gather(const float* z, const float* codebook, const int64_t* idx, int64_t rows, int k, int d,
                             float* zq, double* sse, float* counts, float* esum, void* stream) {
   VG_REQUIRE(z && codebook && idx && zq && rows > 0 && k > 0, "vq_gather: bad arguments");
   VG_REQUIRE(d % 4 == 0 && d / 4 <= 256, "vq_gather: embedding_dim %d unsupported", d);
   VG_REQUIRE((counts == nullptr) == (esum == nullptr), "vq_gather: counts and esum must be given together");
+  const size_t lds = sizeof(float) * ((size_t)k * d + k);
+  if (esum != nullptr && lds <= 144 * 1024 && rows >= 8192) {
+    VG_HIP(hipFuncSetAttribute((const void*)vq_gather_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    const int rpb1 = 1024 / (d / 4);
+    int64_t nb = vg_ceil_div(rows, (int64_t)rpb1 * 16);        // >= 16 rows per thread before a block pays its flush
+    if (nb > 128) nb = 128;
+    hipLaunchKernelGGL(vq_gather_lds_kernel, dim3((unsigned)nb), dim3(1024), lds, (hipStream_t)stream, z, codebook, idx, rows,
+                       k, d, zq, sse, counts, esum);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   const int rpb = 256 / (d / 4);
   int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 4);
   if (blocks > 2048) blocks = 2048;
