@@ -101,6 +101,18 @@ template <typename T> static const char* tname() { return sizeof(T) == 2 ? "bf16
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// LDS-DMA the compiler does not see.  With the builtin it tracks the DMA as a pending LDS write and, because
+// ds_read_b64_tr_b16 (unlike a plain ds_read) carries no alias information, puts `s_waitcnt vmcnt(0)` in front of the
+// first transposed read after every DMA: the weight-gradient kernels then waited, once per tile, for the prefetch they
+// had just issued (a full memory latency per tile; that was the "latency-bound stream").  The kernels order DMA and
+// reads themselves (counted vmcnt + barrier), as they must anyway.  lds_byte_off is wave-uniform.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_byte_off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_off), "v"(gsrc) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
 template <typename T, int MI, int NI, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN;
@@ -1644,6 +1656,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
 
   // ---- DMA pieces of this wave: round r moves piece u = r*8 + wave (wrapped: the spare slots of the last
   // round repeat early pieces, same bytes to the same place, so every wave issues exactly PR per tile)
+  const unsigned smem_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
   unsigned poff[PR];        // byte offset from the tile's origin pixel (dy: (ty0,tx0); x: (ty0-pad, tx0-pad))
   int pyx[PR];              // local (y << 16 | x) of the lane's pixel; y = 0x4000 marks a lane that always reads zeros
   int pdst[PR];             // LDS offset inside a stage (wave-uniform)
@@ -1689,7 +1702,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
       const unsigned char* base = xg + ((long)((long)img * p.H + ty0 - pad) * p.W + tx0 - pad) * p.Cs * 2;
       src = ok ? base + poff[r] : zsrc;
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(smem + stage * STAGE + pdst[r]), 16, 0, 0);
+    lds_dma16(src, smem_base + (unsigned)(stage * STAGE + pdst[r]));
   };
 
   f32x16 acc[NTAPS];
@@ -1867,6 +1880,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   const unsigned char* __restrict__ dyg = (const unsigned char*)p.dy;
   const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
 
+  const unsigned smem_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
   unsigned poff[PR];        // dy: from pixel (ty0, tx0); x: from input pixel (2*ty0 - 1, 2*tx0 - 1)
   int pyx[PR];              // dy: local (y << 16 | x); x: input offset (dy+1 << 16 | dx+1) from that origin; y = 0x4000: zeros
   int pdst[PR];
@@ -1914,7 +1928,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
       const unsigned char* base = xg + ((long)((long)img * p.H + 2 * ty0 - 1) * p.W + 2 * tx0 - 1) * p.Cs * 2;
       src = ok ? base + poff[r] : zsrc;
     }
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(smem + stage * STAGE + pdst[r]), 16, 0, 0);
+    lds_dma16(src, smem_base + (unsigned)(stage * STAGE + pdst[r]));
   };
 
   f32x16 acc[8];            // local tap lt = u*4 + s: kernel row r = 2u + 1 - th, column s
