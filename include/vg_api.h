@@ -44,7 +44,8 @@ typedef struct {
 } vg_conv_desc;
 
 /* Development/ablation switch: 1 = im2col-row implicit GEMM only, 2 = + spatial-tile (halo) kernel where it
- * applies, 3 = + ping-pong spatial-tile kernel where it applies (default). */
+ * applies, 3 = + ping-pong spatial-tile kernel where it applies (default); + 16: the forward of 4x4 stride-2 convs
+ * stays on the im2col-row kernel instead of the parity-plane spatial-tile kernel (A/B timing). */
 void vg_set_conv_kernel(int version);
 /* Same for the weight gradient: 1 = per-tap pixel-reduction kernel only, 3 = + spatial-tile kernel (default). */
 void vg_set_wgrad_kernel(int version);

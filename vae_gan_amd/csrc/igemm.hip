@@ -106,8 +106,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // first transposed read after every DMA: the weight-gradient kernels then waited, once per tile, for the prefetch they
 // had just issued (a full memory latency per tile; that was the "latency-bound stream").  The kernels order DMA and
 // reads themselves (counted vmcnt + barrier), as they must anyway.  lds_byte_off is wave-uniform.
+// M0 (the DMA's LDS base; read when the instruction issues) is put back afterwards: the compiler is not told about it.
 __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_byte_off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte_off), "v"(gsrc) : "memory");
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_byte_off), "v"(gsrc)
+               : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
