@@ -18,12 +18,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, exchange="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from vae_gan_amd.train import DataParallel
-    dp = DataParallel(slice_bytes=4096)            # 1024-element slices -> several all-reduces
-    n = 5000
+    dp = DataParallel(slice_bytes=4096, exchange=exchange)     # 1024-element slices -> several exchanges
+    n = 5001                                       # odd: the last bucket has a remainder the shards do not cover
     g = torch.arange(n, dtype=torch.float32) * (rank + 1)
     opt = types.SimpleNamespace(flat_g=g)
     scale = dp.reduce(opt)
@@ -40,13 +40,26 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_dp_reduce_and_broadcast_world2():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("exchange,world", [("allreduce", 2), ("rsag", 2), ("rsag", 3)])
+def test_dp_reduce_and_broadcast(exchange, world):
+    """Both exchanges (VG_DP_EXCHANGE): one all-reduce per bucket, or reduce-scatter + all-gather on the bucket."""
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, exchange), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_dp_exchange_switch_from_environment(monkeypatch):
+    from vae_gan_amd.train import DataParallel
+    monkeypatch.setenv("VG_DP_EXCHANGE", "rsag")
+    assert DataParallel().exchange == "rsag"
+    monkeypatch.setenv("VG_DP_EXCHANGE", "ring")
+    with pytest.raises(ValueError):
+        DataParallel()
 
 
 def test_single_process_is_identity():

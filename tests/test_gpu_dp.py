@@ -90,6 +90,93 @@ def test_two_ranks_global_statistics_match_single_device_reference():
             assert abs(r0["l2"][k] - r1["l2"][k]) <= 1e-6 * max(ref[0], 1e-6), k      # replicas stay in lock step
 
 
+def _arch_worker(rank, world, port, out, arch, exchange):
+    """One image of the two-image golden per rank, bn_sync='global' (beta_step_256 / hier_step_128)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vae_gan_amd import ops
+    from vae_gan_amd.testing import synthetic_images, hier_step_eps
+    from vae_gan_amd.train import DataParallel, build_optimizers, beta_train_step, hier_train_step
+    ops.set_compute_dtype(torch.float32)
+    if arch == "beta":
+        from vae_gan_amd.beta_vae_gans.config import Config
+        from vae_gan_amd.beta_vae_gans.model import BetaVAEGAN as Model
+        g = load_golden("beta_step_256")
+        images = synthetic_images(2, 256, seed=int(g["images_seed"]))
+    else:
+        from vae_gan_amd.hierarchical_vae_gan.config import Config
+        from vae_gan_amd.hierarchical_vae_gan.model import HierarchicalVAEGAN as Model
+        g = load_golden("hier_step_128")
+        images = as_t(g["images"])
+        eps = hier_step_eps(2, 128)
+    cfg = Config()
+    cfg.recon_target_policy, cfg.hier_decoder_policy = "area", "nearest"
+    model = Model(cfg)
+    sd0 = fill_state_dict(model.state_dict())
+    if rank != 0:                       # only rank 0 starts from the right weights: broadcast_model must fix the others
+        sd0 = {k: (v * 0.5 if v.dtype.is_floating_point else v) for k, v in sd0.items()}
+    model.load_state_dict(sd0)
+    model.cuda().train()
+    dp = DataParallel(bn_sync="global", bucket_bytes=8 << 20, exchange=exchange)
+    dp.broadcast_model(model)
+    opt_g, opt_d, _, _ = build_optimizers(model, cfg)
+    mine = images[rank:rank + 1].cuda()
+    res = {}
+    for it in range(2):
+        if arch == "beta":
+            dl, gl, recon = beta_train_step(model, mine, opt_g, opt_d, dp, eps=as_t(g[f"eps{it}"])[rank:rank + 1].cuda(),
+                                            return_recon=True)
+            assert model.encoder.grad_boundary is None          # the boundary closure does not outlive the step
+        else:
+            pair = [[e[rank:rank + 1].cuda() for e in fwd] for fwd in eps[it]]
+            dl, gl, recon = hier_train_step(model, mine, opt_g, opt_d, dp, eps_lists=pair, return_recon=True)
+        torch.cuda.synchronize()
+        res[it] = {"d_loss": float(dl["total"].detach()), "g_loss": float(gl["total"].detach()), "recon": float(gl["recon"]),
+                   "kl": float(gl["kl"]), "adv": float(gl["adv"]), "d_kl": float(dl["kl"]), "recon_img": recon.detach().cpu()}
+    sd = model.state_dict()
+    res["nbt"] = {k: int(v) for k, v in sd.items() if v.dtype == torch.int64}
+    res["dig"] = {k: digest(k, v)[:3].tolist() for k, v in sd.items() if v.dtype != torch.int64}
+    res["n_async"] = dp.n_async
+    out[rank] = res
+    dp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("arch,exchange,n_async", [("beta", "allreduce", 4), ("hier", "rsag", 2)])
+def test_two_ranks_beta_and_hier_steps_match_single_device_reference(arch, exchange, n_async):
+    """BASELINE configs[2] / configs[3] code paths (beta_vae_gans/main.py:75-108 with the decoder and the two 268 MB
+    Linear layers exchanged from two backward boundaries; hierarchical_vae_gan/main.py:75-111 with the decoder
+    exchanged from one): two ranks, one image each, global-batch statistics, against the single-device two-image
+    goldens made from the REFERENCE modules.  The hierarchical run uses the reduce-scatter + all-gather exchange."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import torch.multiprocessing as mp
+    from conftest import check_step
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_arch_worker, args=(world, _free_port(), out, arch, exchange), nprocs=world, join=True)
+    g = load_golden("beta_step_256" if arch == "beta" else "hier_step_128")
+    r0, r1 = out[0], out[1]
+    assert r0["n_async"] == n_async and r1["n_async"] == n_async      # boundaries fired from inside the backward pass
+    keys = ("d_loss", "g_loss", "recon", "kl", "adv") + (("d_kl",) if arch == "hier" else ())
+    for it in range(2):
+        r = {k: 0.5 * (r0[it][k] + r1[it][k]) for k in keys}       # every loss is a batch mean: average of the halves
+        r["recon_img"] = torch.cat([r0[it]["recon_img"], r1[it]["recon_img"]])
+        check_step(g, it, r, keys)
+    noise = max(float(g["noise:it1_recon_img"]), 1e-4)
+    for key, ref in g.items():
+        if key.startswith("sd:") and key[3:] in r0["nbt"]:
+            assert r0["nbt"][key[3:]] == int(ref) == r1["nbt"][key[3:]], key
+        elif key.startswith("sdd:"):
+            k = key[4:]
+            a, b = r0["dig"][k], r1["dig"][k]
+            assert abs(a[0] - ref[0]) <= max(1e-4, 4 * noise) * max(ref[0], 1e-6), k
+            # replicas stay in lock step: same norm AND same projection on a random probe
+            assert abs(a[0] - b[0]) <= 1e-6 * max(ref[0], 1e-6) and abs(a[2] - b[2]) <= 1e-5 * max(ref[0], 1e-6), k
+
+
 def _worker_rccl(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
@@ -121,17 +208,20 @@ def _worker_rccl(rank, world, port, out):
               "idx": bool(torch.equal(i0, i1)), "grads": float((f0 - f1).norm() / f0.norm()), "n_async": n1}
     # the exchange itself, exactly: a known buffer through the boundary path and through reduce() comes back unchanged
     import types
-    dp = DataParallel(bucket_bytes=1 << 16)
-    dp.world = 2
-    n = 100000
-    params = [torch.nn.Parameter(torch.zeros(60000, device="cuda")), torch.nn.Parameter(torch.zeros(40000, device="cuda"))]
-    flat = torch.arange(n, dtype=torch.float32, device="cuda")
-    opt = types.SimpleNamespace(params=params, offsets=[0, 60000], numel=n, flat_g=flat.clone())
-    x = torch.ones(4, device="cuda", requires_grad=True)
-    dp.mark(x * 2.0, opt, params[1:]).sum().backward()          # fires the boundary: slice [60000, 100000) on the side stream
-    scale = dp.reduce(opt)                                        # sends [0, 60000), waits for both
-    torch.cuda.synchronize()
-    checks["exact_identity"] = bool(torch.equal(opt.flat_g, flat)) and scale == 0.5 and dp.n_async == 1
+    checks["exact_identity"] = True
+    for exchange in ("allreduce", "rsag"):       # rsag: RCCL reduce_scatter_tensor + all_gather_into_tensor, in place
+        dp = DataParallel(bucket_bytes=1 << 16, exchange=exchange)
+        dp.world = 2
+        n = 100000
+        params = [torch.nn.Parameter(torch.zeros(60000, device="cuda")), torch.nn.Parameter(torch.zeros(40000, device="cuda"))]
+        flat = torch.arange(n, dtype=torch.float32, device="cuda")
+        opt = types.SimpleNamespace(params=params, offsets=[0, 60000], numel=n, flat_g=flat.clone())
+        x = torch.ones(4, device="cuda", requires_grad=True)
+        dp.mark(x * 2.0, opt, params[1:]).sum().backward()          # fires the boundary: slice [60000, 100000) on the side stream
+        scale = dp.reduce(opt)                                        # sends [0, 60000), waits for both
+        torch.cuda.synchronize()
+        checks["exact_identity"] = (checks["exact_identity"] and bool(torch.equal(opt.flat_g, flat)) and scale == 0.5
+                                    and dp.n_async == 1)
     out[0] = checks
     dist.destroy_process_group()
 

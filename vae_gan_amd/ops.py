@@ -792,6 +792,7 @@ class LinearFn(torch.autograd.Function):
                                        ws.data_ptr(), L.stream()), "linear_fwd")
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.wparam = weight
         return y
 
     @staticmethod
@@ -813,7 +814,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # dW[o][k] = sum_b gy[b][o] x[b][k]: "pixels" = b
             d = _lin_desc(b, fin, fout)
-            dw = _wgrad(d, x, gy, (fout, fin))
+            dw = _wgrad(d, x, gy, (fout, fin), ctx.wparam)     # inside step_scope: straight into the flat .grad buffer
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(fout, dtype=torch.float32, device=x.device)
             L.check(lib.vg_colsum_f32(gy.data_ptr(), b, fout, db.data_ptr(), L.stream()), "linear.dbias")

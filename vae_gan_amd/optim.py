@@ -50,8 +50,17 @@ class FlatAdam:
     # torch.optim surface used by the training loop
     def zero_grad(self, set_to_none: bool = False):
         self.flat_g.zero_()
-        for p, o in zip(self.params, self.offsets):     # re-attach if someone set .grad = None
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+        base_p, base_g = self.flat_p.data_ptr(), self.flat_g.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != base_p + 4 * o:
+                # someone rebound p.data (model.to(), .float(), a manual assignment): the forward would read that
+                # storage while step() updates flat_p.  Take the new values and alias again.
+                if p.device != self.flat_p.device or p.dtype != torch.float32:
+                    raise RuntimeError("FlatAdam: a parameter left the optimizer's device/dtype; rebuild the optimizers")
+                self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+                self._epoch[0] += 1
+            if p.grad is None or p.grad.data_ptr() != base_g + 4 * o:   # re-attach if someone set .grad = None
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
     def step(self, grad_scale: float = 1.0):

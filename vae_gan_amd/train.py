@@ -6,6 +6,7 @@ that is all-reduced in a few large slices on a side stream while nothing else wa
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Optional
 
 import torch
@@ -39,12 +40,22 @@ class DataParallel:
     whole batch are used on every rank (the sums are added over the ranks before they are finalised, forward and
     backward), which is what the single-device reference computes at the global batch size."""
 
-    def __init__(self, group=None, bucket_bytes: int = 32 << 20, bn_sync: str = "local", slice_bytes: Optional[int] = None):
+    def __init__(self, group=None, bucket_bytes: int = 32 << 20, bn_sync: str = "local", slice_bytes: Optional[int] = None,
+                 exchange: Optional[str] = None):
         if bn_sync not in ("local", "global"):
             raise ValueError("bn_sync must be 'local' or 'global'")
+        exchange = exchange or os.environ.get("VG_DP_EXCHANGE", "allreduce")
+        if exchange not in ("allreduce", "rsag"):
+            raise ValueError("exchange (VG_DP_EXCHANGE) must be 'allreduce' or 'rsag'")
+        # 'allreduce': one all-reduce per bucket (RCCL picks ring / tree).  'rsag': reduce-scatter + all-gather on the
+        # same bucket, in place: over the 7-link xGMI mesh every rank then reduces its own 1/world shard and a link
+        # carries bucket/world bytes per phase instead of the ring's 2*(world-1)/world * bucket through one link
+        # (SURVEY.md §5).  Both give the same sums; the first 8-GPU run A/Bs them with this switch.
+        self.exchange = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._comm_world, self._comm_rank = self.world, self.rank      # the communicator's own size (tests overwrite .world)
         self.bucket_elems = max(1, (slice_bytes or bucket_bytes) // 4)
         self.bn_sync = bn_sync
         self._sent = {}          # id(opt) -> list of (lo, hi) element ranges already exchanged in this phase
@@ -82,6 +93,13 @@ class DataParallel:
                 t.data.copy_(h)
             else:
                 dist.broadcast(t.data, src=0, group=self.group)
+        # the copies went through .data: neither torch's version counter nor the optimizers' epoch cells saw them, so
+        # packed weight images cached by an earlier forward would be stale
+        ops.PARAM_EPOCH[0] += 1
+        for p in model.parameters():
+            cell = getattr(p, "_vg_epoch", None)
+            if cell is not None and cell is not ops.PARAM_EPOCH:
+                cell[0] += 1
 
     # ---- gradient buckets
     @staticmethod
@@ -98,13 +116,39 @@ class DataParallel:
         hi = opt.offsets[idx[-1] + 1] if idx[-1] + 1 < len(opt.params) else opt.numel
         return (lo, hi)
 
+    def _exchange(self, t: torch.Tensor):
+        """Sum the contiguous 1-D bucket ``t`` over the ranks, in place; appends the pending work handles."""
+        w, r = self._comm_world, self._comm_rank
+        n = t.numel()
+        m = n // w * w if self.exchange == "rsag" else 0
+        if m:
+            c = m // w
+            shard = t[r * c:(r + 1) * c]
+            if dist.get_backend(self.group) == "gloo":      # gloo has no reduce-scatter: every rank reduces its own shard
+                for dst in range(w):
+                    dist.reduce(t[dst * c:(dst + 1) * c], dst=dist.get_global_rank(self.group, dst) if self.group else dst,
+                                op=dist.ReduceOp.SUM, group=self.group)
+                self._work.append(dist.all_gather_into_tensor(t[:m], shard.clone(), group=self.group, async_op=True))
+            else:                                            # RCCL: both in place (shard = its slot of the bucket)
+                self._work.append(dist.reduce_scatter_tensor(shard, t[:m], op=dist.ReduceOp.SUM, group=self.group,
+                                                             async_op=True))
+                self._work.append(dist.all_gather_into_tensor(t[:m], shard, group=self.group, async_op=True))
+        if m < n:
+            self._work.append(dist.all_reduce(t[m:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _send(self, opt, lo: int, hi: int):
         if hi <= lo or self.world == 1:
             return
         flat = opt.flat_g
         self._sent.setdefault(id(opt), []).append((lo, hi))
         if flat.is_cuda and self._staged:
-            self.sum_(flat[lo:hi])
+            h = flat[lo:hi].cpu()                # several ranks on one GPU (tests): through the host
+            for s in range(0, hi - lo, self.bucket_elems):
+                self._exchange(h[s:min(s + self.bucket_elems, hi - lo)])
+            for w in self._work:
+                w.wait()
+            self._work.clear()
+            flat[lo:hi].copy_(h)
         elif flat.is_cuda:
             if self._comm is None:
                 self._comm = torch.cuda.Stream(device=flat.device)
@@ -113,12 +157,10 @@ class DataParallel:
             self._comm.wait_event(ev)
             with torch.cuda.stream(self._comm):
                 for s in range(lo, hi, self.bucket_elems):
-                    self._work.append(dist.all_reduce(flat[s:min(s + self.bucket_elems, hi)], op=dist.ReduceOp.SUM,
-                                                      group=self.group, async_op=True))
+                    self._exchange(flat[s:min(s + self.bucket_elems, hi)])
         else:
             for s in range(lo, hi, self.bucket_elems):
-                self._work.append(dist.all_reduce(flat[s:min(s + self.bucket_elems, hi)], op=dist.ReduceOp.SUM,
-                                                  group=self.group, async_op=True))
+                self._exchange(flat[s:min(s + self.bucket_elems, hi)])
 
     def mark(self, x: torch.Tensor, opt: FlatAdam, params) -> torch.Tensor:
         """Boundary on ``x``, the input of the layers that own ``params``: their slice is exchanged as soon as the
@@ -221,7 +263,10 @@ def beta_train_step(model, images, opt_g: FlatAdam, opt_d: FlatAdam, dp: Optiona
             # exchanged as soon as it is complete, under the backward pass of what comes before it in the network.
             enc = model.encoder
             enc.grad_boundary = lambda f: dp.mark(f, opt_g, list(enc.fc_mu.parameters()) + list(enc.fc_logvar.parameters()))
-            z, mu, logvar = model.encode(images, eps)
+            try:
+                z, mu, logvar = model.encode(images, eps)
+            finally:
+                enc.grad_boundary = None        # the closure holds dp and opt_g: never leave it on the module
             recon = model.decode(dp.mark(z, opt_g, model.decoder.parameters()))
         else:
             recon, _, mu, logvar = model(images, eps)
