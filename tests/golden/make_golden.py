@@ -458,7 +458,81 @@ def g_augment():
     save("augment", **out)
 
 
-GROUPS = {"vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
+def _unit_run(u, index, dtype, bf16_storage=False):
+    """One teacher-forced run of unit ``u`` on the reference modules.  bf16_storage: the same float64 arithmetic, but
+    every tensor the HIP engine keeps in bf16 is rounded to bf16 where the engine rounds it: the input, the weights of
+    the convolutions, the output of every leaf module, and (through the casts' own backward) every gradient that
+    crosses a module boundary.  That is the reference itself with bf16 storage: its distance from the float64 run is
+    the floor any bf16 engine has (LeakyReLU masks of pre-activations within bf16 rounding of zero flip)."""
+    from layer_units import unit_input
+    m = load_ref("vq_vae_gan" if u.arch == "vq" else "hierarchical_vae_gan", "model")
+    mod = u.build(m)
+    mod.load_state_dict(fill_state_dict(mod.state_dict(), salt=100 + index))
+    mod = mod.to(dtype).train()
+    rnd = lambda t: t.to(torch.bfloat16).to(t.dtype)
+    hooks = []
+    if bf16_storage:
+        with torch.no_grad():
+            for k, p_ in mod.named_parameters():
+                if p_.dim() >= 2:
+                    p_.copy_(rnd(p_))
+        for leaf in mod.modules():
+            if not list(leaf.children()) and not isinstance(leaf, (torch.nn.LeakyReLU, torch.nn.Sigmoid, torch.nn.Identity)):
+                hooks.append(leaf.register_forward_hook(lambda _m, _i, o: rnd(o)))
+            elif isinstance(leaf, (torch.nn.LeakyReLU, torch.nn.Sigmoid)):
+                hooks.append(leaf.register_forward_hook(lambda _m, _i, o: rnd(o)))
+    x = unit_input(u, index).to(dtype)
+    if bf16_storage:
+        x = rnd(x)
+    x.requires_grad_(True)
+    y = mod(rnd(x) if bf16_storage else x)
+    if bf16_storage:
+        y = rnd(y)
+    cot = cotangent("unit:" + u.name, y.shape).to(dtype)
+    (y * cot).sum().backward()
+    grads = {k: p_.grad.detach().clone() for k, p_ in mod.named_parameters() if p_.grad is not None}
+    bufs = {k: b.detach().clone() for k, b in mod.named_buffers()}
+    for h in hooks:
+        h.remove()
+    return y.detach(), x.grad.detach(), grads, bufs
+
+
+def g_layer_units():
+    """Teacher-forced per-layer fixtures (tests/layer_units.py): for every distinct fused unit the reference's float64
+    output and input gradient (whole-tensor digest + a seeded 16 K-element sample) and the digest of every parameter
+    gradient; 'noise:*' = the reference's own fp32 run against that, 'noise_bf16:*' = the reference with bf16 storage
+    against it, and 'b:*' = that bf16-storage run itself (same rounding points as the engine's bf16 mode, so the
+    LeakyReLU masks coincide and the engine can be held to a tight bound against it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from layer_units import UNITS, sample_index
+    out = {}
+    for index, u in enumerate(UNITS):
+        y64, dx64, g64, b64 = _unit_run(u, index, torch.float64)
+        y32, dx32, g32, _ = _unit_run(u, index, torch.float32)
+        yb, dxb, gb, _ = _unit_run(u, index, torch.float64, bf16_storage=True)
+        n = u.name
+        out[f"{n}:yshape"] = np.array(y64.shape)
+        for tag, t64, t32, tb in (("y", y64, y32, yb), ("dx", dx64, dx32, dxb)):
+            idx = sample_index(n + ":" + tag, t64.numel())
+            out[f"{n}:{tag}:sample"] = t64.flatten()[idx].float()
+            out[f"{n}:{tag}:dig"] = digest(n + ":" + tag, t64)
+            out[f"{n}:noise:{tag}"] = rel_l2(t32, t64)
+            out[f"{n}:noise_bf16:{tag}"] = rel_l2(tb, t64)
+            out[f"{n}:b:{tag}:sample"] = tb.flatten()[idx].float()       # the bf16-storage reference run itself
+            out[f"{n}:b:{tag}:dig"] = digest(n + ":" + tag, tb)
+        for k in g64:
+            out[f"{n}:gd:{k}"] = digest(k, g64[k])
+            out[f"{n}:noise:gd:{k}"] = rel_l2(g32[k], g64[k])
+            out[f"{n}:noise_bf16:gd:{k}"] = rel_l2(gb[k], g64[k])
+            out[f"{n}:b:gd:{k}"] = digest(k, gb[k])
+        for k, v in b64.items():
+            out[f"{n}:buf:{k}"] = v.float() if v.dtype.is_floating_point else v
+        print(n, tuple(y64.shape), {k.split(":", 1)[1]: f"{float(v):.1e}" for k, v in out.items()
+                                    if k.startswith(n + ":noise") and ("dx" in k or "weight" in k)})
+    save("layer_units", **out)
+
+
+GROUPS = {"layer_units": g_layer_units, "vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
           "vq_step": g_vq_step, "losses": g_losses, "beta_modules": g_beta_modules,
           "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step, "vq_codec": g_vq_codec, "augment": g_augment}
 

@@ -144,8 +144,11 @@ def test_module_f32(vg, name):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_module_bf16(vg, name):
-    """bf16 storage + bf16 MFMA: forward within 2e-2 (north_star bf16 tolerance); gradients of these
-    13-27 layer stacks are checked with a looser bound (LeakyReLU sign flips under bf16 rounding)."""
+    """bf16 storage + bf16 MFMA: forward of the whole 13-27 layer stacks within 2e-2 (north_star bf16 tolerance).
+    Gradients in bf16 mode are held layer by layer in tests/test_gpu_layer_grads.py (1e-2 against the reference with
+    bf16 storage, every parameter gradient); through a whole stack the LeakyReLU masks of pre-activations within bf16
+    rounding of zero flip in every layer (the bf16-storage reference itself is 3e-2..5e-2 from float64 after ONE
+    layer, tests/golden/layer_units.npz 'noise_bf16:'), so the stack-level bound on dx is only a sanity check."""
     vg.set_compute_dtype(torch.bfloat16)
     g = load_golden(name)
     inner = _fill(CASES[name]())

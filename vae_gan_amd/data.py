@@ -163,12 +163,18 @@ def _collate_list(batch):
     return list(batch)
 
 
-def get_dataloader(config, split='train'):
-    """data.py:99-141."""
+def get_dataloader(config, split='train', rank=0, world=1):
+    """data.py:99-141.  ``world > 1`` (one process per GPU): every rank reads its own shard of the (shuffled) dataset,
+    ``config.batch_size`` images per rank."""
     set_seed(config.seed)
     train = split == 'train'
     dataset = ImageDataset(config.data_dir, config.dataset, config.image_size, split)
-    loader = DataLoader(dataset, batch_size=config.batch_size if train else config.eval_batch_size, shuffle=train,
+    sampler = None
+    if world > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=train, seed=config.seed)
+    loader = DataLoader(dataset, batch_size=config.batch_size if train else config.eval_batch_size,
+                        shuffle=train and sampler is None, sampler=sampler,
                         num_workers=config.num_workers, pin_memory=True, collate_fn=_collate_list)
     return DeviceLoader(loader, DeviceTransform(config.image_size, train=train))
 

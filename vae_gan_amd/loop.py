@@ -8,9 +8,12 @@ and checkpoints every ``save_interval`` epochs and after the last one (:169-201)
 (:320-328: optimizers, schedulers and the epoch counter are saved but never reloaded); ``load_checkpoint`` does the
 same by default and restores everything with ``full=True``.
 
-Out of scope here, as in DESIGN.md: SSIM / LPIPS / FID (third-party networks), TensorBoard, the entropy coder
-(``compress_image`` raises NameError in the reference); bits per pixel are the reference's closed-form
-estimate (vq_vae_gan/main.py:121-131).
+Bits per pixel (VQ model) are logged like vq_vae_gan/main.py:113-131: every 50th iteration the first image of the
+batch goes through ``compress_image`` (encoder + quantiser in eval mode + the HIP arithmetic coder, vq_vae_gan/codec.py)
+and its true ``metadata['bpp']`` is taken; the iterations in between use the closed-form ``log2(K)`` estimate; the
+evaluation reports the true BPP of every validation image (:249).
+
+Out of scope here, as in DESIGN.md: SSIM / LPIPS / FID (third-party networks) and TensorBoard.
 """
 from __future__ import annotations
 
@@ -40,24 +43,42 @@ def vq_bpp_estimate(indices: torch.Tensor, num_embeddings: int, image_size: int)
     return (indices.shape[1] * indices.shape[2] * math.log2(num_embeddings)) / (image_size * image_size * 3)
 
 
-def evaluate(model, loader: Iterable[torch.Tensor], device="cuda") -> float:
+def vq_true_bpp(model, images: torch.Tensor, device="cuda") -> float:
+    """``compress_image(model, images)['bpp']`` (vq_vae_gan/main.py:115-118): real bytes out of the HIP arithmetic
+    coder.  compress_image switches the model to eval mode (model.py:613); the caller's mode is restored."""
+    from .vq_vae_gan.codec import compress_image
+    was_training = model.training
+    try:
+        with torch.no_grad():
+            _, metadata = compress_image(model, images, device)
+    finally:
+        model.train(was_training)
+    return float(metadata['bpp'])
+
+
+def evaluate(model, loader: Iterable[torch.Tensor], device="cuda", with_bpp: bool = False):
     """Eval-mode forward (running-statistics BatchNorm, no EMA update) + mean PSNR over the loader
     (<arch>/main.py evaluate(), PSNR only).  For the architectures whose reconstruction is half-size the target
-    is the model's documented 'area' target."""
+    is the model's documented 'area' target.  ``with_bpp``: returns (psnr, bpp) with the mean true BPP of the VQ
+    model (vq_vae_gan/main.py:249-250; 0.0 for the other architectures)."""
     was_training = model.training
     model.eval()
-    vals = []
+    vals, bpps = [], []
+    is_vq = hasattr(model, "vector_quantizer")
     with torch.no_grad():
         for images in loader:
             images = images.to(device)
-            out = model(images, training=False) if hasattr(model, "vector_quantizer") else model(images)
+            out = model(images, training=False) if is_vq else model(images)
             recon = out[0]
             target = images
             if recon.shape != images.shape and getattr(model, "recon_target_policy", "error") == "area":
                 target = ops.avg_pool2(images)
             vals.append(psnr(target, recon))
+            if with_bpp and is_vq:
+                bpps.append(vq_true_bpp(model, images, device))
     model.train(was_training)
-    return float(sum(vals) / max(len(vals), 1))
+    value = float(sum(vals) / max(len(vals), 1))
+    return (value, float(sum(bpps) / max(len(bpps), 1))) if with_bpp else value
 
 
 def save_checkpoint(path, epoch, model, opt_g, opt_d, sch_g, sch_d, best_psnr):
@@ -91,11 +112,15 @@ def load_checkpoint(path, model, opt_g=None, opt_d=None, sch_g=None, sch_d=None,
 
 
 def train(model, train_loader, val_loader, config, logger=None, step_fn: Optional[Callable] = None, dp=None,
-          device="cuda"):
+          device="cuda", max_iters: Optional[int] = None, bpp_interval: int = 50):
     """<arch>/main.py train(): returns the trained model; side effects: ``checkpoints/best_model.pth`` and
-    ``checkpoints/latest.pth`` under ``logger.log_dir`` (or ``config.output_dir``)."""
+    ``checkpoints/latest.pth`` under ``logger.log_dir`` (or ``config.output_dir``).  ``dp``: a ``train.DataParallel``;
+    the replicas start from rank 0's parameters and buffers."""
     model = model.to(device)
+    if dp is not None:
+        dp.broadcast_model(model)
     opt_g, opt_d, sch_g, sch_d = T.build_optimizers(model, config)
+    is_vq = hasattr(model, "vector_quantizer")
     if step_fn is None:
         step_fn = (T.vq_train_step if hasattr(model, "vector_quantizer") else
                    T.hier_train_step if hasattr(model, "num_hierarchies") else T.beta_train_step)
@@ -103,8 +128,10 @@ def train(model, train_loader, val_loader, config, logger=None, step_fn: Optiona
     best = 0.0
     for epoch in range(config.epochs):
         model.train()
-        sums, n = {}, 0
+        sums, n, bpps = {}, 0, []
         for i, images in enumerate(train_loader):
+            if max_iters is not None and i >= max_iters:
+                break
             images = images.to(device)
             out = step_fn(model, images, opt_g, opt_d, dp)
             d_loss, g_loss = out[0], out[1]
@@ -112,19 +139,25 @@ def train(model, train_loader, val_loader, config, logger=None, step_fn: Optiona
                 if torch.is_tensor(v):
                     sums[k] = sums.get(k, 0.0) + v.detach()
             n += 1
+            bpp = 0.0
+            if is_vq:                                   # vq_vae_gan/main.py:113-131
+                if i % bpp_interval == 0 and images.shape[0] > 0:
+                    bpp = vq_true_bpp(model, images[:1], device)
+                else:
+                    bpp = vq_bpp_estimate(out[2], config.num_embeddings, config.image_size)
+                bpps.append(bpp)
             if logger is not None and i % config.log_interval == 0 and hasattr(logger, "log_train_metrics"):
-                bpp = vq_bpp_estimate(out[2], config.num_embeddings, config.image_size) if len(out) > 2 else 0.0
                 logger.log_train_metrics(epoch, i, {k: float(v) if torch.is_tensor(v) else v for k, v in g_loss.items()}, bpp)
         sch_g.step()
         sch_d.step()
         avg = {k: float(v) / max(n, 1) for k, v in sums.items()}
         print(f"Epoch {epoch + 1}/{config.epochs} - G Loss: {avg.get('total', float('nan')):.4f}, "
-              f"D Loss: {avg.get('disc', float('nan')):.4f}")
+              f"D Loss: {avg.get('disc', float('nan')):.4f}" + (f", BPP: {sum(bpps) / len(bpps):.4f}" if bpps else ""))
         if (epoch + 1) % config.save_interval == 0 or epoch == config.epochs - 1:
-            value = evaluate(model, val_loader, device) if val_loader is not None else 0.0
-            print(f"Validation - PSNR: {value:.2f}")
+            value, eval_bpp = evaluate(model, val_loader, device, with_bpp=True) if val_loader is not None else (0.0, 0.0)
+            print(f"Validation - PSNR: {value:.2f}" + (f", BPP: {eval_bpp:.4f}" if is_vq else ""))
             if logger is not None and hasattr(logger, "log_eval_metrics"):
-                logger.log_eval_metrics(epoch, value, 0.0, 0.0, 0.0, 0.0)
+                logger.log_eval_metrics(epoch, value, 0.0, 0.0, 0.0, eval_bpp)
             if (not dp or dp.rank == 0):
                 os.makedirs(out_dir, exist_ok=True)
                 if value > best:

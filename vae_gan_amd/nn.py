@@ -108,24 +108,32 @@ class Sigmoid(nn.Module):
 
 
 class ResidualBlock(nn.Module):
-    """beta_vae_gans/model.py:11-40 (identical in the other two model.py files).
-    Only in_channels == out_channels occurs (Identity skip)."""
+    """beta_vae_gans/model.py:11-40 (identical in the other two model.py files).  Every call site of the reference
+    uses in_channels == out_channels (Identity skip); with different widths the skip is the reference's 1x1 conv
+    (model.py:24-25)."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__()
-        if in_channels != out_channels:
-            raise NotImplementedError("ResidualBlock with a 1x1 skip conv is never built by the reference models")
         self.conv1 = Conv2d(in_channels, out_channels, 3, padding=1)
         self.conv2 = Conv2d(out_channels, out_channels, 3, padding=1)
         self.bn1 = BatchNorm2d(out_channels)
         self.bn2 = BatchNorm2d(out_channels)
         self.relu = LeakyReLU(0.2)
         self.skip = nn.Identity()
+        if in_channels != out_channels:
+            self.skip = Conv2d(in_channels, out_channels, 1)
 
     def forward(self, x):
         train = self.training
         l1 = ops.BiasLink(self.conv1.bias) if train else None
         l2 = ops.BiasLink(self.conv2.bias) if train else None
+        if isinstance(self.skip, Conv2d):
+            # x fans out to conv1 and the skip conv: their two input gradients are added by the HIP add kernel
+            xa, xb = ops.fan_out(x)
+            h, st = self.conv1.run(xa, want_stats=train, link=l1)
+            h = self.bn1.run(h, st, L.ACT_LRELU, link=l1)
+            h, st = self.conv2.run(h, want_stats=train, link=l2)
+            return self.bn2.run(h, st, L.ACT_LRELU, res=self.skip(xb), link=l2)
         rl = ops.ResLink() if (train and x.requires_grad) else None
         h, st = self.conv1.run(x, want_stats=train, link=l1, reslink=rl)
         h = self.bn1.run(h, st, L.ACT_LRELU, link=l1)

@@ -558,6 +558,27 @@ def grad_boundary(x: torch.Tensor, fn) -> torch.Tensor:
     return GradBoundaryFn.apply(x, fn) if (torch.is_grad_enabled() and x.requires_grad) else x
 
 
+class FanOutFn(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two consumers; the backward adds the two gradients with the HIP add kernel
+    (left to autograd, the sum would be one of torch's elementwise kernels)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        out = ga.contiguous().clone()
+        L.check(L.load().vg_add_inplace(out.data_ptr(), gb.contiguous().data_ptr(), out.numel(), L.vg_dtype(out.dtype), L.stream()), "add")
+        return out
+
+
+def fan_out(x: torch.Tensor):
+    return FanOutFn.apply(x) if (torch.is_grad_enabled() and x.requires_grad) else (x, x)
+
+
 class AddFn(torch.autograd.Function):
     """a + b on NHWC activations (hand-written kernel; used where a block output fans in)."""
 
