@@ -13,7 +13,8 @@ Rank 0 prints ONE JSON line: whole-job train images/s (weak scaling: 64 images p
    HIP-event-timed launch durations, against the 2.5 PFLOP/s dense bf16 MFMA peak; "traffic" = its
    HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json);
  * "cpu_baseline": the CPU oracle's train step (oracle/vaegan_oracle.py, a port of the reference
-   step) timed on this host on a bounded sample (N=1, rank 0 only).
+   step) timed on this host on a bounded sample (N=1, rank 0 only): one same-size warm-up, median of 3;
+   "cpu_baseline_configs0": the same protocol on BASELINE.json configs[0] (beta-VAE-GAN, batch 16).
 """
 import argparse
 import glob
@@ -32,20 +33,46 @@ GF_PER_IMG_LITERAL = 446.9         # reference schedule, fwd F
 GF_PER_IMG_NECESSARY = 391.7       # same minus D-wgrad in the G phase and the repeated encoder fwd
 
 
-def cpu_baseline(batch, size, threads):
-    """One oracle train step (after one untimed step at the smallest size to warm torch) on CPU."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(arch, batch, size, threads, repeats=3):
+    """the CPU oracle's train step (oracle/vaegan_oracle.py, a port of the reference step: the
+    reference's Python cannot travel to the GPU box), fp32, ``threads`` torch threads: ONE untimed warm-up step of
+    the same size, then the MEDIAN of ``repeats`` timed steps.  arch 'vq' = the workload of the metric;
+    'beta' = BASELINE.json configs[0] (batch 16, 256x256, one train step on the CPU path; NON-REFERENCE shim D1:
+    the reference's own beta step raises)."""
     from oracle import vaegan_oracle as O
-    from vae_gan_amd.testing import fill_state_dict, synthetic_images
+    from vae_gan_amd.testing import fill_state_dict, synthetic_images, synthetic_eps
     torch.set_num_threads(threads)
-    sd = fill_state_dict(O.vq_template())
     imgs = synthetic_images(batch, size, seed=7)
     opt = {"g": {}, "d": {}}
-    O.vq_train_step(sd, synthetic_images(1, 32, seed=8), O.VQ_DEFAULT_CFG, {"g": {}, "d": {}})
-    t0 = time.perf_counter()
-    O.vq_train_step(sd, imgs, O.VQ_DEFAULT_CFG, opt)
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"1 oracle train step (D+G, fp32, torch CPU), batch {batch} at {size}x{size}, {dt:.1f} s"}
+    if arch == "vq":
+        sd = fill_state_dict(O.vq_template())
+        step = lambda: O.vq_train_step(sd, imgs, O.VQ_DEFAULT_CFG, opt)
+        what = "VQ-VAE-GAN"
+    else:
+        sd = fill_state_dict(O.beta_template())
+        eps = synthetic_eps((batch, 128), 9)
+        step = lambda: O.beta_train_step(sd, imgs, eps, O.BETA_DEFAULT_CFG, opt)
+        what = "beta-VAE-GAN (configs[0]; shim D1: area-downsampled target)"
+    step()                                           # warm-up, same size
+    times = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": batch / dt, "unit": "images/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"{what} oracle train step (D+G, fp32, torch CPU), batch {batch} at {size}x{size}: 1 warm-up step, "
+                      f"median of {repeats} timed steps = {dt:.2f} s (all: {', '.join(f'{t:.2f}' for t in times)})"}
 
 
 def main():
@@ -203,7 +230,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.arch == "vq":
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-            out["cpu_baseline"] = cpu_baseline(16, args.size, threads)
+            out["cpu_baseline"] = cpu_baseline("vq", 16, args.size, threads)
+            if args.size == 256:      # BASELINE.json configs[0]: the reference's own CPU-runnable case
+                out["cpu_baseline_configs0"] = cpu_baseline("beta", 16, 256, threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

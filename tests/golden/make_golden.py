@@ -461,8 +461,10 @@ def g_augment():
 def _unit_run(u, index, dtype, bf16_storage=False):
     """One teacher-forced run of unit ``u`` on the reference modules.  bf16_storage: the same float64 arithmetic, but
     every tensor the HIP engine keeps in bf16 is rounded to bf16 where the engine rounds it: the input, the weights of
-    the convolutions, the output of every leaf module, and (through the casts' own backward) every gradient that
-    crosses a module boundary.  That is the reference itself with bf16 storage: its distance from the float64 run is
+    the convolutions, the output of every convolution and of every activation (NOT of a BatchNorm: the engine fuses
+    normalise (+ residual) + LeakyReLU and rounds once, after the activation; rounding the BatchNorm output before the
+    residual add would move the LeakyReLU mask of ~0.06 % of a ResidualBlock's outputs), and (through the casts' own
+    backward) every gradient that crosses such a boundary.  That is the reference itself with bf16 storage: its distance from the float64 run is
     the floor any bf16 engine has (LeakyReLU masks of pre-activations within bf16 rounding of zero flip)."""
     from layer_units import unit_input
     m = load_ref("vq_vae_gan" if u.arch == "vq" else "hierarchical_vae_gan", "model")
@@ -477,9 +479,7 @@ def _unit_run(u, index, dtype, bf16_storage=False):
                 if p_.dim() >= 2:
                     p_.copy_(rnd(p_))
         for leaf in mod.modules():
-            if not list(leaf.children()) and not isinstance(leaf, (torch.nn.LeakyReLU, torch.nn.Sigmoid, torch.nn.Identity)):
-                hooks.append(leaf.register_forward_hook(lambda _m, _i, o: rnd(o)))
-            elif isinstance(leaf, (torch.nn.LeakyReLU, torch.nn.Sigmoid)):
+            if isinstance(leaf, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.LeakyReLU, torch.nn.Sigmoid)):
                 hooks.append(leaf.register_forward_hook(lambda _m, _i, o: rnd(o)))
     x = unit_input(u, index).to(dtype)
     if bf16_storage:

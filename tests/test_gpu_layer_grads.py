@@ -5,9 +5,15 @@ held, on its output, its input gradient and EVERY parameter-gradient digest (l2 
 
   * f32 mode: 1e-4 against the reference's float64 run (north_star's fp32 tolerance; the reference's own fp32 run is
     ~1e-6 from it, so this is tight);
-  * bf16 mode: 1e-2 against the reference run WITH bf16 STORAGE ('b:' entries: same float64 arithmetic, tensors rounded
-    to bf16 where the engine rounds them).  Masks of LeakyReLU coincide there, so a systematic error of a percent in
-    any bf16 kernel shows;
+  * bf16 mode against the reference run WITH bf16 STORAGE ('b:' entries: same float64 arithmetic, tensors rounded to
+    bf16 where the engine rounds them), where the LeakyReLU masks coincide except for a handful of elements: output
+    within 2e-3 (measured: bit-identical for the thin layers, <= 7e-4 everywhere), input gradient within 5e-3 once
+    the 0.2 % worst elements are set aside and 2.5e-2 with them, every parameter gradient's norm within 1e-2 and its
+    probe dot within 4e-2.  (The engine accumulates a K = 9*C dot product in f32, the reference in f64: 1-3 % of the
+    conv outputs land on the other side of a bf16 rounding boundary, and of those ~5 per LeakyReLU layer sit close
+    enough to zero to flip their mask: 8e-3 on the input gradient of ResidualBlock(64), 1.6e-2 on ResidualBlock(256),
+    tests/gpu_layer_diag.py prints the table.)  A systematic error of a percent in any bf16 kernel shows in the
+    trimmed bound and in the norms;
   * bf16 mode against the float64 run: north_star's 2e-2 where the unit has no LeakyReLU.  Behind a LeakyReLU the
     bf16-storage reference ITSELF sits 2.6e-2..5.1e-2 from float64 ('noise_bf16:' entries: pre-activations within bf16
     rounding of zero change their mask, ~0.1 % of the elements, each moving its gradient by 80 %), which no
@@ -49,7 +55,17 @@ def _run_unit(vg, index):
     return u, g, y.detach().cpu(), x.grad.cpu(), {k: p.grad.detach().cpu() for k, p in mod.named_parameters()}
 
 
-def _check(u, g, y, dx, grads, prefix, tol_of):
+def _trimmed_rel_l2(a, b, frac):
+    """rel-L2 with the ``frac`` largest per-element deviations set aside (mask flips touch a handful of elements)."""
+    a, b = torch.as_tensor(a, dtype=torch.float64).flatten(), torch.as_tensor(b, dtype=torch.float64).flatten()
+    e2 = (a - b) ** 2
+    k = int(frac * e2.numel())
+    if k:
+        e2 = e2.sort().values[:-k]
+    return float((e2.sum() / (b ** 2).sum().clamp_min(1e-300)).sqrt())
+
+
+def _check(u, g, y, dx, grads, prefix, tol_of, zero_tol=1e-3, trimmed=None):
     """prefix '' = float64 reference, 'b:' = bf16-storage reference.  Returns the worst error / tolerance ratio."""
     n, worst = u.name, 0.0
     for tag, t in (("y", y), ("dx", dx)):
@@ -57,6 +73,9 @@ def _check(u, g, y, dx, grads, prefix, tol_of):
         tol = tol_of(tag)
         e = rel_l2(t.flatten()[idx], g[f"{n}:{prefix}{tag}:sample"])
         assert e <= tol, f"{n}.{tag}: rel-L2 {e:.3e} > {tol:.1e}"
+        if trimmed is not None:
+            et = _trimmed_rel_l2(t.flatten()[idx], g[f"{n}:{prefix}{tag}:sample"], 0.002)
+            assert et <= trimmed, f"{n}.{tag}: rel-L2 without the 0.2 % worst elements {et:.3e} > {trimmed:.1e}"
         d, ref = digest(n + ":" + tag, t), g[f"{n}:{prefix}{tag}:dig"]
         assert abs(d[0] - ref[0]) <= tol * ref[0] and abs(d[2] - ref[2]) <= 4 * tol * ref[0], f"{n}.{tag} digest"
         worst = max(worst, e / tol)
@@ -65,7 +84,7 @@ def _check(u, g, y, dx, grads, prefix, tol_of):
         sib = g.get(f"{n}:{prefix}gd:" + k[:-4] + "weight") if k.endswith(".bias") else None
         d = digest(k, t)
         if sib is not None and g[f"{n}:gd:{k}"][0] < 1e-4 * g[f"{n}:gd:" + k[:-4] + "weight"][0]:
-            assert d[0] < 1e-3 * sib[0], f"{n}.{k}: expected ~0 gradient (conv bias in front of a BatchNorm)"
+            assert d[0] < zero_tol * sib[0], f"{n}.{k}: expected ~0 gradient (conv bias in front of a BatchNorm)"
             continue
         if k == "key.bias":       # softmax-invariant: rounding noise on every implementation (tests/test_gpu_hier.py)
             continue
@@ -88,9 +107,11 @@ def test_unit_bf16(vg, index):
     vg.set_compute_dtype(torch.bfloat16)
     try:
         u, g, y, dx, grads = _run_unit(vg, index)
-        # (1) against the reference with bf16 storage: tight, the LeakyReLU masks coincide
-        _check(u, g, y, dx, grads, "b:", lambda what: 1e-2)
+        # (1) against the reference with bf16 storage: the LeakyReLU masks coincide up to a handful of elements
+        # (a conv bias in front of a BatchNorm: the sum of the bf16 rounding errors of dx, ~1e-3 of the weight gradient)
+        _check(u, g, y, dx, grads, "b:", lambda what: {"y": 2e-3, "dx": 2.5e-2}.get(what, 1e-2), zero_tol=1e-2,
+               trimmed=1e-2 if "attention" in u.name else 5e-3)    # attention: P is rounded to bf16 for the P.V MFMA
         # (2) against the float64 reference: 2e-2, or 1.5x the bf16-storage floor of the reference itself
-        _check(u, g, y, dx, grads, "", lambda what: max(2e-2, 1.5 * float(g[f"{u.name}:noise_bf16:{what}"])))
+        _check(u, g, y, dx, grads, "", lambda what: max(2e-2, 1.5 * float(g[f"{u.name}:noise_bf16:{what}"])), zero_tol=1e-2)
     finally:
         vg.set_compute_dtype(torch.float32)
