@@ -7,8 +7,9 @@ held, on its output, its input gradient and EVERY parameter-gradient digest (l2 
     ~1e-6 from it, so this is tight);
   * bf16 mode against the reference run WITH bf16 STORAGE ('b:' entries: same float64 arithmetic, tensors rounded to
     bf16 where the engine rounds them), where the LeakyReLU masks coincide except for a handful of elements: output
-    within 2e-3 (measured: bit-identical for the thin layers, <= 7e-4 everywhere), input gradient within 5e-3 once
-    the 0.2 % worst elements are set aside and 2.5e-2 with them, every parameter gradient's norm within 1e-2 and its
+    within 2e-3 (measured: bit-identical for the thin layers, <= 7e-4 everywhere), input gradient within 1e-2 once
+    the 0.2 % worst elements are set aside (measured <= 7e-3: a flipped element of the second LeakyReLU spreads over
+    the 9*C inputs of the convolution behind it) and 2.5e-2 with them, every parameter gradient's norm within 1e-2 and its
     probe dot within 4e-2.  (The engine accumulates a K = 9*C dot product in f32, the reference in f64: 1-3 % of the
     conv outputs land on the other side of a bf16 rounding boundary, and of those ~5 per LeakyReLU layer sit close
     enough to zero to flip their mask: 8e-3 on the input gradient of ResidualBlock(64), 1.6e-2 on ResidualBlock(256),
@@ -110,7 +111,7 @@ def test_unit_bf16(vg, index):
         # (1) against the reference with bf16 storage: the LeakyReLU masks coincide up to a handful of elements
         # (a conv bias in front of a BatchNorm: the sum of the bf16 rounding errors of dx, ~1e-3 of the weight gradient)
         _check(u, g, y, dx, grads, "b:", lambda what: {"y": 2e-3, "dx": 2.5e-2}.get(what, 1e-2), zero_tol=1e-2,
-               trimmed=1e-2 if "attention" in u.name else 5e-3)    # attention: P is rounded to bf16 for the P.V MFMA
+               trimmed=1e-2)
         # (2) against the float64 reference: 2e-2, or 1.5x the bf16-storage floor of the reference itself
         _check(u, g, y, dx, grads, "", lambda what: max(2e-2, 1.5 * float(g[f"{u.name}:noise_bf16:{what}"])), zero_tol=1e-2)
     finally:
