@@ -94,6 +94,15 @@ int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* d
 int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws, int accumulate,
                    void* stream);
 
+/* vg_channel_sum for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): no counterpart in the reference.  Same result as vg_channel_sum; the f64 replica scratch is a
+ * static device array inside the library (256 KiB per GPU, held until the process ends), so there is no `ws`
+ * argument and the call allocates nothing.  Limit: cs <= 1024 (VG_ERR_BAD_ARG beyond, with a message).  All calls on
+ * one GPU share that array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream are
+ * ordered and each clears what it uses. */
+int vg_channel_sum_noalloc(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, int accumulate,
+                           void* stream);
+
 /* ---- layout ------------------------------------------------------------------------------ */
 /* NCHW f32 [n][c][h][w]  <->  NHWC `dtype` [n][h][w][cs] (channels >= c written as zero). */
 int vg_nchw_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int cs, int dtype, void* stream);

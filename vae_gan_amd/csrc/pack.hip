@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include <mutex>
 
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -213,6 +214,62 @@ extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, 
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_sum: channel stride %d unsupported", cs);
   hipStream_t st = (hipStream_t)stream;
   VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * cs * VG_STATS_REPLICAS, st));
+  const int ppr = cs / piece, rpb = 256 / ppr;
+  int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 16);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, rows, cs, ws);
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws);
+  VG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(d2f_kernel, dim3((c_valid + 255) / 256), dim3(256), 0, st, (const double*)ws, out, c_valid, 1.0,
+                     VG_STATS_REPLICAS, cs, accumulate);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vg_channel_sum without the caller's workspace and without any allocation: for callers that cannot allocate (code
+// under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The f64 replica scratch the kernel
+// accumulates into lives in a file-scope device array.  On the host the array's NAME is only a stand-in, not a
+// device address: its address is taken ONCE per device with hipGetSymbolAddress (that device current) and only that
+// pointer is ever handed to a kernel or a memset.  Every GPU holds its own copy at its own address until the process
+// ends.  All calls on one GPU share the array (it keeps the last call's contents: each call clears the part it uses
+// first, on its stream), so calls that overlap on one GPU race.
+// ---------------------------------------------------------------------------------------------
+#define VG_NOALLOC_MAX_CS 1024       // 32 replicas x 1024 channels x 8 B = 256 KiB per GPU
+#define VG_MAX_DEVICES 64
+static __device__ __align__(256) double vg_scratch[VG_STATS_REPLICAS * VG_NOALLOC_MAX_CS];
+static double* g_scratch_ptr[VG_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+static int scratch_of_current_device(double** out) {
+  int dev = -1;
+  VG_HIP(hipGetDevice(&dev));
+  VG_REQUIRE(dev >= 0 && dev < VG_MAX_DEVICES, "channel_sum_noalloc: device ordinal %d outside [0, %d)", dev, VG_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    VG_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(vg_scratch)));
+    VG_REQUIRE(p != nullptr, "channel_sum_noalloc: hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[dev] = (double*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return VG_OK;
+}
+
+extern "C" int vg_channel_sum_noalloc(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out,
+                                      int accumulate, void* stream) {
+  VG_REQUIRE(a && out && rows > 0 && cs > 0 && c_valid > 0 && c_valid <= cs, "channel_sum_noalloc: bad arguments");
+  VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "channel_sum_noalloc: bad dtype %d", dtype);
+  VG_REQUIRE(cs <= VG_NOALLOC_MAX_CS, "channel_sum_noalloc: channel stride %d exceeds the static scratch (max %d); use "
+             "vg_channel_sum with a caller workspace", cs, VG_NOALLOC_MAX_CS);
+  const int piece = dtype == VG_BF16 ? 8 : 4;
+  VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_sum_noalloc: channel stride %d unsupported", cs);
+  double* ws = nullptr;
+  int rc = scratch_of_current_device(&ws);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * cs * VG_STATS_REPLICAS, st));      // the replicas must start at zero
   const int ppr = cs / piece, rpb = 256 / ppr;
   int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 16);
   if (blocks > 2048) blocks = 2048;

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vg_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
     "vg_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
     "vg_channel_sum": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _P]),
+    "vg_channel_sum_noalloc": (_I, [_P, _L, _I, _I, _I, _P, _I, _P]),
     "vg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_nhwc_to_nchw": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "vg_avgpool2_nchw": (_I, [_P, _P, _L, _I, _I, _P]),
