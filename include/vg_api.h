@@ -60,6 +60,14 @@ size_t vg_conv_packed_bytes(const vg_conv_desc* d, int transposed);
  * Replaces the implicit weight layout handling inside torch's conv (e.g. vq_vae_gan/model.py:146). */
 int vg_conv_pack_weight(const vg_conv_desc* d, int transposed, const float* w_oihw, void* packed, void* stream);
 
+/* The same for many layers in one launch (all packed images of one optimizer after its step).  vg_conv_pack_item
+ * fills one table entry of vg_conv_pack_item_bytes() bytes on the HOST for (desc, transposed, master weight, packed
+ * image); the caller copies the table to the device once (the pointers do not change between steps) and
+ * vg_conv_pack_batch re-packs all `n_items` entries, which must share `dtype`. */
+size_t vg_conv_pack_item_bytes(void);
+int vg_conv_pack_item(const vg_conv_desc* d, int transposed, const float* w_oihw, void* packed, void* item);
+int vg_conv_pack_batch(const void* items_dev, int n_items, int dtype, void* stream);
+
 /* ---- the three conv primitives ----------------------------------------------------------- */
 /* y = act(conv(x, W) + bias) [+ y if accumulate].  `stats` (optional): f64 [VG_STATS_REPLICAS][2][Npad]
  * zeroed by the caller; receives per-channel sum / sum of squares of the (dtype-rounded) pre-activation

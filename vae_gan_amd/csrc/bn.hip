@@ -283,7 +283,7 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
                                    const float* __restrict__ mean,
                                    float* __restrict__ coef /* [3][cpad]: dx = ca*dz - cb - cx*x */,
-                                   float* dgamma, float* dbeta, int accumulate, float dgb_scale) {
+                                   float* dgamma, float* dbeta, int accumulate, float dgb_scale, float* dxsum) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
   double s1 = 0.0, s2 = 0.0;
@@ -300,6 +300,11 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
   const float g2 = (float)(s2 * (double)dgb_scale), g1 = (float)(s1 * (double)dgb_scale);
   if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + g2 : g2;
   if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + g1 : g1;
+  // Per-channel sum of dx (the bias gradient of the conv in front of this BatchNorm) in closed form, when the sums are
+  // those of the rows this rank holds (count = rows):  sum dx = ca*S1 - rows*cb - cx*Sx  with Sx = rows*mean collapses to
+  // a*(S1 - rows*m1).  Mathematically zero; what is left is the rounding of m1 to float, i.e. the same kind of noise the
+  // reference's autograd leaves there, but without a pass over dx, without atomics, and reproducible.
+  if (dxsum) dxsum[ch] += (float)((double)a * (s1 - count * (double)m1));
 }
 
 template <typename T, bool HAS_DRES, bool XMASK>
@@ -400,8 +405,12 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   hipStream_t st = (hipStream_t)stream;
   // coefficient scratch lives right behind the f64 sums (caller allocates [REPLICAS*2*cpad] f64 + 3*cpad f32)
   float* coef = (float*)(sums + (size_t)VG_STATS_REPLICAS * 2 * cpad);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)(count > 0 ? count : rows), gamma, invstd, mean, coef, dgamma, dbeta, accumulate, dgb_scale);
+  // local statistics (count = rows): the bias gradient comes out of the coefficient kernel in closed form; with
+  // global-batch statistics (count > rows) the rank's own sum of dx is not zero and the apply kernel adds it up.
+  const bool closed = dxsum != nullptr && (count <= 0 || count == rows);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)(count > 0 ? count : rows), gamma, invstd, mean, coef, dgamma, dbeta, accumulate, dgb_scale, closed ? dxsum : (float*)nullptr);
   VG_LAUNCH_CHECK();
+  if (closed) dxsum = nullptr;
   const int ppr = cs / piece;
   const int64_t np = rows;
   int nblocks = row_blocks(rows, 256 / ppr, 16);               // >= 16 rows per thread: the coefficient preamble amortises

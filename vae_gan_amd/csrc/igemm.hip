@@ -2101,7 +2101,16 @@ __global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restri
     const long ors = t / I;
     const int rs = (int)(ors % RS), o = (int)(ors / RS);
     const float* src = packed + (size_t)ors * Cpad + i;
-    for (int g = gy; g < parts; g += 4) v += src[(size_t)g * part_elems];
+    // eight loads in flight per thread (the partial images are megabytes apart: one dependent chain of loads per
+    // thread left the kernel latency-bound); the order of the additions is fixed, so the sum is reproducible
+    int g = gy;
+    float a[8];
+    for (; g + 28 < parts; g += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(g + 4 * u) * part_elems];
+      v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    for (; g < parts; g += 4) v += src[(size_t)g * part_elems];
     dst = ((long)o * I + i) * RS + rs;
   }
   red[gy][e] = v;

@@ -50,6 +50,9 @@ SIGNATURES = {
     "vg_last_conv_kernel": (C.c_char_p, []),
     "vg_conv_packed_bytes": (C.c_size_t, [_DP, _I]),
     "vg_conv_pack_weight": (_I, [_DP, _I, _P, _P, _P]),
+    "vg_conv_pack_item_bytes": (C.c_size_t, []),
+    "vg_conv_pack_item": (_I, [_DP, _I, _P, _P, _P]),
+    "vg_conv_pack_batch": (_I, [_P, _I, _I, _P]),
     "vg_conv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vg_conv_splitk_ws_bytes": (C.c_size_t, [_DP]),
     "vg_conv_fwd_splitk": (_I, [_DP, _P, _P, _P, _P, _I, _I, _P, _P]),

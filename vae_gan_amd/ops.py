@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os as _os
+import weakref
 from typing import Optional
 
 import torch
@@ -150,17 +151,78 @@ def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------------------------
+class RepackTable:
+    """Every packed weight image whose master weight belongs to ONE optimizer (it hangs on the epoch cell the fused
+    optimizer shares with its parameters).  ``FlatAdam.step`` calls ``run()`` once: all images are re-packed by a
+    single launch (``vg_conv_pack_batch``) instead of one ~7 us launch per layer on its next forward / backward.
+    Entries hold weak references: a layer or parameter that is gone drops out (its buffers may have been freed)."""
+
+    def __init__(self):
+        self.entries = []          # [ref(PackedWeights), key, ref(weight), item bytes, dtype, weight data_ptr]
+        self.tables = {}           # dtype -> (device table, n)
+        self.dirty = True
+
+    def add(self, owner, key, weight, desc, transposed, buf, dt):
+        lib = L.load()
+        item = (C.c_ubyte * lib.vg_conv_pack_item_bytes())()
+        L.check(lib.vg_conv_pack_item(C.byref(desc), transposed, weight.data_ptr(), buf.data_ptr(), item), "pack_item")
+        self.entries = [e for e in self.entries if not (e[0]() is owner and e[1] == key)]      # its old image is gone
+        self.entries.append((weakref.ref(owner), key, weakref.ref(weight), bytes(item), dt, weight.data_ptr()))
+        self.dirty = True
+
+    def run(self):
+        live = []
+        for e in self.entries:
+            owner, weight = e[0](), e[2]()
+            if owner is None or weight is None or weight.data_ptr() != e[5] or e[1] not in owner.cache:
+                self.dirty = True          # dropped: the pointers in its table entry may dangle
+                continue
+            live.append(e)
+        self.entries = live
+        if not live:
+            return
+        lib = L.load()
+        if self.dirty:
+            self.tables = {}
+            dev = live[0][2]().device
+            for dt in {e[4] for e in live}:
+                raw = b"".join(e[3] for e in live if e[4] == dt)
+                self.tables[dt] = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev), sum(1 for e in live if e[4] == dt))
+            self.dirty = False
+        for dt, (table, n) in self.tables.items():
+            L.check(lib.vg_conv_pack_batch(table.data_ptr(), n, L.vg_dtype(dt), L.stream()), "pack_batch")
+        for e in live:                     # the cached images are current again
+            owner, weight = e[0](), e[2]()
+            owner.cache[e[1]] = (PackedWeights.tag(weight), owner.cache[e[1]][1])
+
+
+class EpochCell(list):
+    """``[n]``: bumped by a fused optimizer whenever its parameters change; carries the optimizer's RepackTable."""
+
+    def __init__(self, n):
+        super().__init__([n])
+        self.table = RepackTable()
+
+
+def repack_all(epoch_cell) -> None:
+    epoch_cell.table.run()
+
+
 class PackedWeights:
     """Per-layer cache of the packed (and transposed-packed) weight images in the compute dtype."""
 
     def __init__(self):
         self.cache = {}
 
-    def get(self, weight: torch.Tensor, desc: L.ConvDesc, transposed: int, dt: torch.dtype) -> torch.Tensor:
-        key = (transposed, dt, desc.stride, desc.pad)
+    @staticmethod
+    def tag(weight):
         # a fused optimizer bumps the epoch cell it shares with ITS parameters (the D step does not invalidate the
         # generator's packed weights and vice versa); everything else shows up in torch's version counter
-        tag = (weight._version, getattr(weight, "_vg_epoch", PARAM_EPOCH)[0], weight.data_ptr())
+        return (weight._version, getattr(weight, "_vg_epoch", PARAM_EPOCH)[0], weight.data_ptr())
+
+    def get(self, weight: torch.Tensor, desc: L.ConvDesc, transposed: int, dt: torch.dtype) -> torch.Tensor:
+        key = (transposed, dt, desc.stride, desc.pad)
+        tag = self.tag(weight)
         hit = self.cache.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
@@ -168,9 +230,13 @@ class PackedWeights:
         nbytes = lib.vg_conv_packed_bytes(C.byref(desc), transposed)
         if nbytes == 0:
             raise RuntimeError("conv: unsupported geometry for weight packing: " + L.last_error())
-        buf = torch.empty(nbytes // (2 if dt == torch.bfloat16 else 4), dtype=dt, device=weight.device)
+        fresh = hit is None or hit[1].numel() * hit[1].element_size() != nbytes or hit[0][2] != tag[2]
+        buf = torch.empty(nbytes // (2 if dt == torch.bfloat16 else 4), dtype=dt, device=weight.device) if fresh else hit[1]
         L.check(lib.vg_conv_pack_weight(C.byref(desc), transposed, weight.data_ptr(), buf.data_ptr(), L.stream()), "pack_weight")
         self.cache[key] = (tag, buf)
+        cell = getattr(weight, "_vg_epoch", None)
+        if fresh and isinstance(cell, EpochCell):   # from now on the optimizer's step re-packs it with all the others
+            cell.table.add(self, key, weight, desc, transposed, buf, dt)
         return buf
 
 
@@ -315,6 +381,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None, reslink=None):
         _require_cuda(x, "conv2d")
+        ctx.set_materialize_grads(False)    # else autograd zero-fills a gradient for the (non-differentiable) statistics
         ctx.link, ctx.reslink = link, reslink
         x = x.contiguous()
         n, h, w, xcs = x.shape
@@ -339,6 +406,8 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gstats):
+        if gy is None:
+            return (None,) * 10
         x, weight, y = ctx.saved_tensors
         d, lib = ctx.d, L.load()
         gy = gy.contiguous()
@@ -370,6 +439,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None):
         _require_cuda(x, "conv_transpose2d")
+        ctx.set_materialize_grads(False)
         ctx.link = link
         x = x.contiguous()
         n, h, w, xcs = x.shape
@@ -397,6 +467,8 @@ class ConvTranspose2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gstats):
+        if gy is None:
+            return (None,) * 9
         x, weight, y = ctx.saved_tensors
         d, lib = ctx.d, L.load()
         gy = gy.contiguous()
@@ -616,7 +688,7 @@ class VectorQuantizeFn(torch.autograd.Function):
         L.check(lib.vg_vq_assign(flat.data_ptr(), codebook.data_ptr(), rows, k, d, idx.data_ptr(), norms.data_ptr(),
                                  L.stream()), "vq_assign")
         zq_flat = torch.empty_like(flat)
-        scal = torch.zeros(2, dtype=torch.float64, device=dev)       # [sse, unused]
+        scal = _zeros_f64(2, dev)       # [sse, unused]
         counts = esum = None
         if training:
             buf = torch.zeros(k * (d + 1) + 1, dtype=torch.float32, device=dev)
@@ -671,7 +743,7 @@ class MSEFn(torch.autograd.Function):
         n = a.numel()
         if n % 4:
             raise RuntimeError("mse: element count must be a multiple of 4")
-        acc = torch.zeros(1, dtype=torch.float64, device=a.device)
+        acc = _zeros_f64(1, a.device)
         L.check(L.load().vg_sqdiff_sum(a.data_ptr(), b.data_ptr(), n // 4, 4, 4, L.VG_F32, acc.data_ptr(), L.stream()), "sqdiff_sum")
         ctx.save_for_backward(a, b)
         return _finish(acc, 1.0 / n)
@@ -700,7 +772,7 @@ class MeanFn(torch.autograd.Function):
     def forward(ctx, x, mode, scale):
         _require_cuda(x, "mean")
         x = x.contiguous().float()
-        acc = torch.zeros(1, dtype=torch.float64, device=x.device)
+        acc = _zeros_f64(1, x.device)
         L.check(L.load().vg_reduce_f32(x.data_ptr(), x.numel(), mode, acc.data_ptr(), L.stream()), "reduce_f32")
         ctx.mode, ctx.scale = mode, scale
         ctx.save_for_backward(x)
@@ -758,7 +830,7 @@ class KLFn(torch.autograd.Function):
     def forward(ctx, mu, logvar):
         _require_cuda(mu, "kl")
         mu, logvar = mu.contiguous().float(), logvar.contiguous().float()
-        acc = torch.zeros(1, dtype=torch.float64, device=mu.device)
+        acc = _zeros_f64(1, mu.device)
         L.check(L.load().vg_reparam_kl_fwd(mu.data_ptr(), logvar.data_ptr(), None, mu.numel(), None, acc.data_ptr(),
                                            L.stream()), "kl")
         ctx.save_for_backward(mu, logvar)

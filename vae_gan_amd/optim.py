@@ -42,7 +42,7 @@ class FlatAdam:
             p.data = self.flat_p[o:o + n].view(p.shape)
             p.grad = self.flat_g[o:o + n].view(p.shape)
         # packed-weight caches (ops.PackedWeights) of these parameters are keyed on this cell: bumped by step()
-        self._epoch = [ops.PARAM_EPOCH[0] + 1]
+        self._epoch = ops.EpochCell(ops.PARAM_EPOCH[0] + 1)
         for p in self.params:
             p._vg_epoch = self._epoch
         ops.PARAM_EPOCH[0] += 1
@@ -69,6 +69,7 @@ class FlatAdam:
                                       self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1],
                                       self.eps, self.step_count, grad_scale, L.stream()), "adam_step")
         self._epoch[0] += 1
+        ops.repack_all(self._epoch)         # every packed weight image of these parameters, one launch
 
     @property
     def param_groups(self):
