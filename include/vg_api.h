@@ -87,6 +87,30 @@ int vg_conv_fwd_splitk(const vg_conv_desc* d, const void* x, const void* w_packe
  * (vq_vae_gan/model.py:186; beta_vae_gans/model.py:123).  w_packed is the transposed image. */
 int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
                   double* stats, int act, int accumulate, void* stream);
+
+/* The input-gradient launch of the layer that CONSUMED a BatchNorm's output produces that BatchNorm's upstream
+ * gradient; these variants also take the BatchNorm backward sums (per channel: sum dz, sum dz*xhat, with
+ * dz = dout * LeakyReLU'(.)) in the kernel's epilogue, replacing one vg_bn_bwd_reduce pass over two tensors
+ * (torch.nn.BatchNorm2d's backward inside every Sequential of <arch>/model.py, e.g. vq_vae_gan/model.py:143-158).
+ * x: the BatchNorm's raw input, same NHWC layout as the gradient being written; y: its output (only when the mask
+ * must be read there: residual BatchNorm), else the mask is x*scale+shift > 0; sums: f64
+ * [VG_STATS_REPLICAS][2][cpad], zeroed by the caller.  *fused = 1 when the kernel variant that ran took the sums
+ * (the ping-pong spatial-tile kernels, bf16); 0 otherwise: sums untouched, call vg_bn_bwd_reduce. */
+typedef struct vg_bn_bwd_stats {
+  const void* x;
+  const void* y;
+  const float* mean;
+  const float* invstd;
+  const float* scale;
+  const float* shift;
+  double* sums;
+  int cpad;
+  int act;
+} vg_bn_bwd_stats;
+int vg_conv_dgrad_bnstats(const vg_conv_desc* d, const void* dy, const void* w_packed_t, void* dx, int accumulate,
+                          const vg_bn_bwd_stats* bs, int* fused, void* stream);
+int vg_conv_fwd_bnstats(const vg_conv_desc* d, const void* x, const void* w_packed, void* y, int accumulate,
+                        const vg_bn_bwd_stats* bs, int* fused, void* stream);
 /* dW[O][I][R][S] (f32, OIHW) = sum over pixels of dy ⊗ im2col(x).  `ws` is f32 scratch of
  * vg_conv_wgrad_ws_bytes(d) bytes (one packed image of dW for the per-tap kernel; up to ~75 MB for the spatial-tile
  * kernels, which write one partial image per tile group with plain stores and sum them in a fixed order: no

@@ -58,3 +58,89 @@ def test_spatial_tile_weight_gradient_is_bit_reproducible(gpu, case):
     L.check(lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), acc.data_ptr(), ws.data_ptr(), 1, L.stream()), "wgrad")
     torch.cuda.synchronize()
     assert torch.equal(acc, outs[0] * 2)
+
+
+def _bn_vec(c, cpad_unused, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    mean = 0.3 * torch.randn(c, device="cuda", generator=g)
+    invstd = 0.5 + torch.rand(c, device="cuda", generator=g)
+    scale = invstd * (0.75 + 0.5 * torch.rand(c, device="cuda", generator=g))
+    shift = 0.2 * torch.randn(c, device="cuda", generator=g) - mean * scale
+    return mean, invstd, scale, shift
+
+
+# (n, h, w, ci, co, k, stride, pad, accumulate, mask from y): ci = channels of the BatchNorm whose gradient dx is
+@pytest.mark.parametrize("case", [(4, 64, 64, 64, 64, 3, 1, 1, 0, False), (4, 64, 64, 64, 64, 3, 1, 1, 1, True),
+                                  (2, 32, 64, 128, 128, 3, 1, 1, 1, False), (2, 32, 32, 256, 512, 3, 1, 1, 0, True),
+                                  (2, 64, 64, 64, 128, 4, 2, 1, 0, True), (2, 40, 36, 64, 64, 3, 1, 1, 0, False),
+                                  (2, 64, 64, 64, 3, 3, 1, 1, 0, False)],
+                         ids=lambda c: "n%d_%dx%d_ci%d_co%d_k%ds%dp%d_acc%d_y%d" % c)
+def test_dgrad_bnstats_matches_separate_reduce(gpu, case):
+    """vg_conv_dgrad_bnstats: the input-gradient kernel takes the BatchNorm backward sums of the tile it writes.  Same
+    dx bits as vg_conv_dgrad, and the sums equal vg_bn_bwd_reduce run on that dx (full and ragged tiles, accumulate
+    onto a parked skip gradient, stride-2 phases, mask recomputed from x or read from y, thin 3-channel consumer)."""
+    import ctypes as C
+    from vae_gan_amd import lib as L
+    n, h, w, ci, co, k, stride, pad, acc, from_y = case
+    lib = L.load()
+    dt = torch.bfloat16
+    d = G.make_desc(n, h, w, ci, co, k, stride, pad, dt)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    wt = (torch.randn(co, ci, k, k, device="cuda", generator=g) / (ci * k * k) ** 0.5).contiguous()
+    wpt = G.pack(lib, d, wt, 1, dt)
+    gy = torch.zeros(n, d.oh, d.ow, d.ycs, device="cuda", dtype=dt)
+    gy[..., :co] = torch.randn(n, d.oh, d.ow, co, device="cuda", generator=g).to(dt)
+    xraw = torch.zeros(n, h, w, d.xcs, device="cuda", dtype=dt)             # the BatchNorm's raw input
+    xraw[..., :ci] = torch.randn(n, h, w, ci, device="cuda", generator=g).to(dt)
+    ybn = torch.zeros_like(xraw)                                            # its output (sign = activation mask)
+    ybn[..., :ci] = torch.randn(n, h, w, ci, device="cuda", generator=g).to(dt)
+    parked = torch.zeros_like(xraw)
+    parked[..., :ci] = torch.randn(n, h, w, ci, device="cuda", generator=g).to(dt)
+    mean, invstd, scale, shift = _bn_vec(ci, 0, 5)
+    cpad = 32 if ci <= 32 else (64 if ci <= 64 else (ci + 127) // 128 * 128)
+    # reference: plain dgrad, then the separate reduction pass over (dx, x)
+    dx0 = parked.clone()
+    L.check(lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx0.data_ptr(), None, L.ACT_NONE, acc, L.stream()), "dgrad")
+    want = torch.zeros(L.STATS_REPLICAS * 2 * cpad, dtype=torch.float64, device="cuda")
+    L.check(lib.vg_bn_bwd_reduce(dx0.data_ptr(), ybn.data_ptr() if from_y else None, xraw.data_ptr(), mean.data_ptr(),
+                                 invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), want.data_ptr(), n * h * w, d.xcs, ci,
+                                 cpad, L.ACT_LRELU, L.VG_BF16, L.stream()), "bn_bwd_reduce")
+    # fused
+    dx1 = parked.clone()
+    got = torch.zeros_like(want)
+    bs = L.BnBwdStats(x=xraw.data_ptr(), y=ybn.data_ptr() if from_y else None, mean=mean.data_ptr(), invstd=invstd.data_ptr(),
+                      scale=scale.data_ptr(), shift=shift.data_ptr(), sums=got.data_ptr(), cpad=cpad, act=L.ACT_LRELU)
+    fused = C.c_int(-1)
+    L.check(lib.vg_conv_dgrad_bnstats(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx1.data_ptr(), acc, C.byref(bs),
+                                      C.byref(fused), L.stream()), "dgrad_bnstats")
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    assert fused.value == 1, lib.vg_last_conv_kernel()
+    a = want.view(L.STATS_REPLICAS, 2, cpad).sum(0)
+    b = got.view(L.STATS_REPLICAS, 2, cpad).sum(0)
+    scale_ = a.abs().max(dim=1, keepdim=True).values
+    assert float(((a - b).abs() / scale_).max()) <= 2e-6, float(((a - b).abs() / scale_).max())
+    assert float(b[:, ci:].abs().max()) == 0.0 if cpad > ci else True
+
+
+def test_dgrad_bnstats_reports_unfused_kernels(gpu):
+    """Kernel variants without the fused sums (f32 parity mode, narrow images) leave the sums alone and say so."""
+    import ctypes as C
+    from vae_gan_amd import lib as L
+    lib = L.load()
+    d = G.make_desc(2, 16, 16, 64, 64, 3, 1, 1, torch.bfloat16)          # 16 pixels wide: not a ping-pong tile shape
+    g = torch.Generator(device="cuda").manual_seed(1)
+    wt = torch.randn(64, 64, 3, 3, device="cuda", generator=g)
+    wpt = G.pack(lib, d, wt, 1, torch.bfloat16)
+    gy = torch.randn(2, 16, 16, 64, device="cuda", generator=g).bfloat16()
+    xraw = torch.randn(2, 16, 16, 64, device="cuda", generator=g).bfloat16()
+    dx = torch.empty_like(xraw)
+    mean, invstd, scale, shift = _bn_vec(64, 0, 2)
+    sums = torch.zeros(L.STATS_REPLICAS * 2 * 64, dtype=torch.float64, device="cuda")
+    bs = L.BnBwdStats(x=xraw.data_ptr(), y=None, mean=mean.data_ptr(), invstd=invstd.data_ptr(), scale=scale.data_ptr(),
+                      shift=shift.data_ptr(), sums=sums.data_ptr(), cpad=64, act=L.ACT_LRELU)
+    fused = C.c_int(-1)
+    L.check(lib.vg_conv_dgrad_bnstats(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx.data_ptr(), 0, C.byref(bs), C.byref(fused),
+                                      L.stream()), "dgrad_bnstats")
+    torch.cuda.synchronize()
+    assert fused.value == 0 and float(sums.abs().max()) == 0.0 and torch.isfinite(dx.float()).all()

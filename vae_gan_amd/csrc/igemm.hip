@@ -50,6 +50,12 @@ struct IgemmParams {
   // LDS-DMA ring on every step.)
   unsigned long long dyp[VG_MAX_PHASES], dxp[VG_MAX_PHASES];
   int dymin_i[VG_MAX_PHASES], dxmin_i[VG_MAX_PHASES];
+  // igemm3 epilogue, optional: y is the gradient of a BatchNorm's OUTPUT (this launch is the input-gradient kernel of
+  // the layer that consumed it); take the BatchNorm backward sums (sum dz, sum dz*xhat per channel) while the tile is
+  // still on chip instead of a separate two-tensor pass (bn_bwd_reduce).  bs_x = the BatchNorm's raw input, same
+  // layout as y; bs_y = its output when the activation mask has to come from there (residual BatchNorm), else the mask
+  // is recomputed as x*scale+shift > 0 like the forward pass did.
+  vg_bn_bwd_stats bs;
 };
 
 static void pack_taps(IgemmParams& p) {
@@ -682,7 +688,11 @@ struct Igemm3Cfg {
   static constexpr int WTILE = 32 * 32 * NI * EB;             // per-wave epilogue staging: one 32-row block
   static constexpr int PIPE = NSH * HBYTES + NSB * BSTRIDE;
   static constexpr int MAINB = PIPE > 8 * WTILE ? PIPE : 8 * WTILE;
-  static constexpr int LDS = MAINB + BM * 4 + WM * BN * 2 * 4;
+  // [4][BN] f32 BatchNorm-backward coefficients (epilogue only): behind the epilogue staging tiles inside the then idle
+  // pipeline area when there is room (every configuration in use), else appended
+  static constexpr bool COEF_INSIDE = MAINB >= 8 * WTILE + 4 * BN * 4;
+  static constexpr int COEF_OFF = COEF_INSIDE ? 8 * WTILE : MAINB + BM * 4 + WM * BN * 2 * 4;
+  static constexpr int LDS = MAINB + BM * 4 + WM * BN * 2 * 4 + (COEF_INSIDE ? 0 : 4 * BN * 4);
   static constexpr bool FITS = LDS <= 160 * 1024 && (NSH == 2 || HRN <= 2 * NTAPS);
 };
 
@@ -939,9 +949,47 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   }
   const bool fast = sizeof(T) == 2 && ty0 + TH <= p.OHl && tx0 + TW <= p.OWl && n0 + BN <= p.Nout && p.act != VG_ACT_SIGMOID;
   const bool want_stats = p.stats != nullptr;
+  // BatchNorm-backward sums of the tile (see IgemmParams::bs): coefficients of this block's channels go to LDS once,
+  // every lane keeps the partial sums of ITS 16-byte channel piece (lane % PPR is the same in every store round)
+  const bool bs = p.bs.x != nullptr;
+  float* coef = (float*)(smem + Cfg::COEF_OFF);       // [scale | shift | invstd | mean*invstd][BN]
+  float bs1[PIECE], bs2[PIECE];
+#pragma unroll
+  for (int e = 0; e < PIECE; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
+  if (bs) {
+    for (int c = tid; c < BN; c += NT) {
+      const int n = n0 + c;
+      const bool ok = n < p.Nout;
+      const float is = ok ? p.bs.invstd[n] : 0.f;
+      coef[c] = (ok && p.bs.scale) ? p.bs.scale[n] : 0.f;
+      coef[BN + c] = (ok && p.bs.shift) ? p.bs.shift[n] : 0.f;
+      coef[2 * BN + c] = is;
+      coef[3 * BN + c] = ok ? p.bs.mean[n] * is : 0.f;
+    }
+    __syncthreads();
+  }
+  constexpr int ROUNDS = 32 * PPR / 64;          // store rounds of one 32-row block: 16-byte piece lane + 64*rd
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const unsigned* rp = rowpix + (wm * MI + i) * 32;
+    // BatchNorm-backward sums: this block's pieces of the raw BatchNorm input (and of its output when the mask comes
+    // from there) are requested NOW, before the accumulators are converted and staged, so that their memory latency
+    // runs under that work (loaded right where they are used, every store round stalled for a full latency)
+    Piece<T> xr[ROUNDS], yr[ROUNDS];
+    asm volatile("" ::: "memory");      // keep the requests of block i behind the stores of block i-1 (register pressure)
+    if (bs) {
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int q = lane + 64 * rd;
+        const int lrow = q / PPR, pc = q - lrow * PPR;
+        const unsigned pix = rp[lrow];
+        const int n = n0 + wn * WN_COLS + pc * PIECE;
+        const bool ok = pix != 0xFFFFFFFFu && n < p.Ks;
+        const size_t off = ok ? (size_t)pix * p.Ks + n : 0;
+        xr[rd].v = *(const decltype(xr[rd].v)*)((const T*)p.bs.x + off);
+        if (p.bs.y != nullptr) yr[rd].v = *(const decltype(yr[rd].v)*)((const T*)p.bs.y + off);
+      }
+    }
     if (fast) {
       T* wl = wt + 4 * h * WN_COLS + l32;          // lane base; everything else below is an immediate
       auto lean = [&](auto LR, auto ST) {
@@ -991,7 +1039,9 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int q = lane; q < 32 * PPR; q += 64) {
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+      const int q = lane + 64 * rd;
       const int lrow = q / PPR, pc = q - lrow * PPR;
       const unsigned pix = rp[lrow];
       const int n = n0 + wn * WN_COLS + pc * PIECE;
@@ -1006,9 +1056,47 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         for (int e = 0; e < PIECE; ++e) o.set(e, o.get(e) + old.get(e));
       }
       *(decltype(o.v)*)dst = o.v;
+      if (bs) {        // o = the gradient as stored (what the BatchNorm backward will read)
+        const float* cf = coef + wn * WN_COLS + pc * PIECE;
+#pragma unroll
+        for (int e = 0; e < PIECE; ++e) {
+          const float xf = xr[rd].get(e);
+          float dz = o.get(e);
+          const float pre = p.bs.y != nullptr ? yr[rd].get(e) : xf * cf[e] + cf[BN + e];
+          if (p.bs.act == VG_ACT_LRELU && !(pre > 0.f)) dz *= VG_LRELU_SLOPE;
+          bs1[e] += dz;
+          bs2[e] += dz * (xf * cf[2 * BN + e] - cf[3 * BN + e]);
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+  }
+  if (bs) {
+    // lanes lane, lane + PPR, ... hold the same channel piece: fold them, then the WM waves of a column through LDS
+#pragma unroll
+    for (int m = PPR; m < 64; m <<= 1) {
+#pragma unroll
+      for (int e = 0; e < PIECE; ++e) { bs1[e] += __shfl_xor(bs1[e], m, 64); bs2[e] += __shfl_xor(bs2[e], m, 64); }
+    }
+    if (lane < PPR) {
+#pragma unroll
+      for (int e = 0; e < PIECE; ++e) {
+        const int col = wn * WN_COLS + lane * PIECE + e;
+        red[(wm * BN + col) * 2 + 0] = bs1[e];
+        red[(wm * BN + col) * 2 + 1] = bs2[e];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Nout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+      const int rep = (mtile + phase) % VG_STATS_REPLICAS;
+      unsafeAtomicAdd(&p.bs.sums[((size_t)rep * 2 + 0) * p.bs.cpad + n0 + tid], (double)t1);
+      unsafeAtomicAdd(&p.bs.sums[((size_t)rep * 2 + 1) * p.bs.cpad + n0 + tid], (double)t2);
+    }
+    __syncthreads();
   }
   VG_STAMP(3);
   if (want_stats) {
@@ -1257,13 +1345,31 @@ static int check_desc(const vg_conv_desc* d) {
 
 static int cpad_of(int c, int dtype) { int kc = kc_of(dtype); return (int)vg_ceil_div(c, kc) * kc; }
 
-extern "C" int vg_conv_fwd(const vg_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
-                           double* stats, int act, int accumulate, void* stream) {
+// BatchNorm-backward sums in the epilogue: only the ping-pong spatial-tile kernels implement them.  Returns whether
+// the launch that just ran took them (g_last_kernel names it).
+static int check_bs(const vg_bn_bwd_stats* bs, int nout) {
+  VG_REQUIRE(bs->x && bs->mean && bs->invstd && bs->sums, "conv bnstats: x, mean, invstd and sums are required");
+  VG_REQUIRE(bs->y || (bs->scale && bs->shift) || bs->act != VG_ACT_LRELU,
+             "conv bnstats: the LeakyReLU mask needs y, or scale and shift to recompute it from x");
+  VG_REQUIRE(bs->act == VG_ACT_NONE || bs->act == VG_ACT_LRELU, "conv bnstats: activation %d unsupported", bs->act);
+  VG_REQUIRE(bs->cpad >= nout, "conv bnstats: cpad %d < %d channels", bs->cpad, nout);
+  return VG_OK;
+}
+static bool last_kernel_takes_bs() { return strncmp(g_last_kernel, "igemm3", 6) == 0; }
+
+static int conv_fwd_impl(const vg_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                         double* stats, int act, int accumulate, const vg_bn_bwd_stats* bs, int* fused, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   VG_REQUIRE(x && w_packed && y, "conv_fwd: null pointer");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
+  if (fused) *fused = 0;
+  if (bs) {
+    rc = check_bs(bs, d->co);
+    if (rc) return rc;
+    if (bias == nullptr && stats == nullptr && act == VG_ACT_NONE && d->dtype == VG_BF16) p.bs = *bs;
+  }
   p.x = x; p.w = w_packed; p.bias = bias; p.y = y; p.stats = stats;
   p.N = d->n; p.H = d->h; p.W = d->w; p.C = cpad_of(d->ci, d->dtype); p.Cs = d->xcs;
   p.OHl = d->oh; p.OWl = d->ow; p.OH = d->oh; p.OW = d->ow; p.Ks = d->ycs;
@@ -1273,7 +1379,20 @@ extern "C" int vg_conv_fwd(const vg_conv_desc* d, const void* x, const void* w_p
   p.M = d->n * d->oh * d->ow;
   for (int r = 0; r < d->r; ++r)
     for (int s = 0; s < d->s; ++s) { p.dy[0][r * d->s + s] = (signed char)(r - d->pad); p.dx[0][r * d->s + s] = (signed char)(s - d->pad); }
-  return d->dtype == VG_BF16 ? dispatch_igemm<bf16_t>(p, (hipStream_t)stream) : dispatch_igemm<float>(p, (hipStream_t)stream);
+  rc = d->dtype == VG_BF16 ? dispatch_igemm<bf16_t>(p, (hipStream_t)stream) : dispatch_igemm<float>(p, (hipStream_t)stream);
+  if (rc == VG_OK && fused && p.bs.x != nullptr && last_kernel_takes_bs()) *fused = 1;
+  return rc;
+}
+
+extern "C" int vg_conv_fwd(const vg_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                           double* stats, int act, int accumulate, void* stream) {
+  return conv_fwd_impl(d, x, w_packed, bias, y, stats, act, accumulate, nullptr, nullptr, stream);
+}
+
+extern "C" int vg_conv_fwd_bnstats(const vg_conv_desc* d, const void* x, const void* w_packed, void* y, int accumulate,
+                                   const vg_bn_bwd_stats* bs, int* fused, void* stream) {
+  VG_REQUIRE(bs && fused, "conv_fwd_bnstats: null pointer");
+  return conv_fwd_impl(d, x, w_packed, nullptr, y, nullptr, VG_ACT_NONE, accumulate, bs, fused, stream);
 }
 
 // ---- split-K forward: few output tiles but a long reduction (Linear layers viewed as 1x1 convs over
@@ -1342,8 +1461,8 @@ extern "C" int vg_conv_fwd_splitk(const vg_conv_desc* d, const void* x, const vo
   return VG_OK;
 }
 
-extern "C" int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
-                             double* stats, int act, int accumulate, void* stream) {
+static int conv_dgrad_impl(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
+                           double* stats, int act, int accumulate, const vg_bn_bwd_stats* bs, int* fused, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   VG_REQUIRE(dy && w_packed_t && dx, "conv_dgrad: null pointer");
@@ -1351,6 +1470,12 @@ extern "C" int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* 
   VG_REQUIRE(d->h % s == 0 && d->w % s == 0, "conv_dgrad: input %dx%d not a multiple of stride %d", d->h, d->w, s);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
+  if (fused) *fused = 0;
+  if (bs) {
+    rc = check_bs(bs, d->ci);
+    if (rc) return rc;
+    if (bias == nullptr && stats == nullptr && act == VG_ACT_NONE && d->dtype == VG_BF16) p.bs = *bs;
+  }
   p.x = dy; p.w = w_packed_t; p.bias = bias; p.y = dx; p.stats = stats;
   p.N = d->n; p.H = d->oh; p.W = d->ow; p.C = cpad_of(d->co, d->dtype); p.Cs = d->ycs;
   p.OHl = d->h / s; p.OWl = d->w / s; p.OH = d->h; p.OW = d->w; p.Ks = d->xcs;
@@ -1365,7 +1490,20 @@ extern "C" int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* 
     nt = n;
   }
   p.ntaps = nt;
-  return d->dtype == VG_BF16 ? dispatch_igemm<bf16_t>(p, (hipStream_t)stream) : dispatch_igemm<float>(p, (hipStream_t)stream);
+  rc = d->dtype == VG_BF16 ? dispatch_igemm<bf16_t>(p, (hipStream_t)stream) : dispatch_igemm<float>(p, (hipStream_t)stream);
+  if (rc == VG_OK && fused && p.bs.x != nullptr && last_kernel_takes_bs()) *fused = 1;
+  return rc;
+}
+
+extern "C" int vg_conv_dgrad(const vg_conv_desc* d, const void* dy, const void* w_packed_t, const float* bias, void* dx,
+                             double* stats, int act, int accumulate, void* stream) {
+  return conv_dgrad_impl(d, dy, w_packed_t, bias, dx, stats, act, accumulate, nullptr, nullptr, stream);
+}
+
+extern "C" int vg_conv_dgrad_bnstats(const vg_conv_desc* d, const void* dy, const void* w_packed_t, void* dx, int accumulate,
+                                     const vg_bn_bwd_stats* bs, int* fused, void* stream) {
+  VG_REQUIRE(bs && fused, "conv_dgrad_bnstats: null pointer");
+  return conv_dgrad_impl(d, dy, w_packed_t, nullptr, dx, nullptr, VG_ACT_NONE, accumulate, bs, fused, stream);
 }
 
 // =============================================================================================

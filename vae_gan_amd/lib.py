@@ -34,6 +34,11 @@ _D = C.c_double
 _DP = C.POINTER(ConvDesc)
 
 
+class BnBwdStats(C.Structure):
+    """vg_bn_bwd_stats of include/vg_api.h."""
+    _fields_ = [(n, C.c_void_p) for n in ("x", "y", "mean", "invstd", "scale", "shift", "sums")] + [("cpad", C.c_int), ("act", C.c_int)]
+
+
 class AugItem(C.Structure):
     _fields_ = [("src", C.c_void_p)] + [(n, C.c_int) for n in
                                          ("height", "width", "flip_h", "flip_v", "crop_i", "crop_j", "crop_h", "crop_w")]
@@ -57,6 +62,8 @@ SIGNATURES = {
     "vg_conv_splitk_ws_bytes": (C.c_size_t, [_DP]),
     "vg_conv_fwd_splitk": (_I, [_DP, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vg_conv_dgrad": (_I, [_DP, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "vg_conv_dgrad_bnstats": (_I, [_DP, _P, _P, _P, _I, C.POINTER(BnBwdStats), C.POINTER(C.c_int), _P]),
+    "vg_conv_fwd_bnstats": (_I, [_DP, _P, _P, _P, _I, C.POINTER(BnBwdStats), C.POINTER(C.c_int), _P]),
     "vg_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
     "vg_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
     "vg_channel_sum": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _P]),

@@ -38,7 +38,7 @@ class Conv2d(nn.Module):
 
     def run(self, x, act=L.ACT_NONE, want_stats=False, link=None, reslink=None):
         return ops.Conv2dFn.apply(x, self.weight, self.bias, self.stride, self.padding, act, want_stats, self._packs, link,
-                                  reslink)
+                                  reslink, ops.claim_bwdstat(x))
 
     def forward(self, x):
         return self.run(x)[0]
@@ -60,7 +60,7 @@ class ConvTranspose2d(nn.Module):
 
     def run(self, x, act=L.ACT_NONE, want_stats=False, link=None):
         return ops.ConvTranspose2dFn.apply(x, self.weight, self.bias, self.stride, self.padding, act, want_stats, self._packs,
-                                           link)
+                                           link, ops.claim_bwdstat(x))
 
     def forward(self, x):
         return self.run(x)[0]
@@ -86,8 +86,12 @@ class BatchNorm2d(nn.Module):
             return ops.bn_eval_act(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, act, c, res)
         if stats is None:
             stats = ops.channel_stats(x.contiguous(), c)
-        return ops.BNActFn.apply(x, stats, self.weight, self.bias, res, self.running_mean, self.running_var,
-                                 self.num_batches_tracked, self.eps, self.momentum, act, c, link, reslink)
+        bsl = ops.BwdStatLink() if (torch.is_grad_enabled() and x.requires_grad) else None
+        y = ops.BNActFn.apply(x, stats, self.weight, self.bias, res, self.running_mean, self.running_var,
+                              self.num_batches_tracked, self.eps, self.momentum, act, c, link, reslink, bsl)
+        if bsl is not None:
+            y._vg_bwdstat = bsl         # used only once a container armed it (ops.BwdStatLink)
+        return y
 
     def forward(self, x):
         return self.run(x, None)
@@ -132,11 +136,13 @@ class ResidualBlock(nn.Module):
             xa, xb = ops.fan_out(x)
             h, st = self.conv1.run(xa, want_stats=train, link=l1)
             h = self.bn1.run(h, st, L.ACT_LRELU, link=l1)
+            ops.arm_bwdstat(h)
             h, st = self.conv2.run(h, want_stats=train, link=l2)
             return self.bn2.run(h, st, L.ACT_LRELU, res=self.skip(xb), link=l2)
         rl = ops.ResLink() if (train and x.requires_grad) else None
         h, st = self.conv1.run(x, want_stats=train, link=l1, reslink=rl)
         h = self.bn1.run(h, st, L.ACT_LRELU, link=l1)
+        ops.arm_bwdstat(h)              # bn1 feeds conv2 and nothing else
         h, st = self.conv2.run(h, want_stats=train, link=l2)
         return self.bn2.run(h, st, L.ACT_LRELU, res=x, link=l2, reslink=rl)
 
@@ -149,6 +155,8 @@ class FusedSequential(nn.Sequential):
         mods = list(self)
         i, n = 0, len(mods)
         while i < n:
+            if i > 0:
+                ops.arm_bwdstat(x)      # the output of one element feeds the next element and nothing else
             m = mods[i]
             if isinstance(m, (Conv2d, ConvTranspose2d)):
                 j = i + 1

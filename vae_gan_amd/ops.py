@@ -368,6 +368,47 @@ class ResLink:
         self.dres = None
 
 
+class BwdStatLink:
+    """Ties a training-mode BatchNorm to the ONE layer that consumes its output.  That layer's input-gradient launch
+    writes the BatchNorm's upstream gradient, so it can take the BatchNorm backward sums (sum dz, sum dz*xhat) in
+    its epilogue (``vg_conv_dgrad_bnstats`` / ``vg_conv_fwd_bnstats``); the BatchNorm backward then skips its own
+    two-tensor reduction pass.  The link rides on the BatchNorm's output tensor (``_vg_bwdstat``) and is only used
+    when a container that knows the topology armed it (FusedSequential: element k feeds element k+1 and nothing
+    else; ResidualBlock: bn1 feeds conv2) and exactly one convolution claimed it."""
+    __slots__ = ("x", "y", "vec", "c", "cpad", "act", "armed", "claims", "sums", "fused")
+
+    def __init__(self):
+        self.x = self.y = self.vec = self.sums = None
+        self.c = self.cpad = self.act = 0
+        self.armed, self.claims, self.fused = False, 0, False
+
+
+def arm_bwdstat(t) -> None:
+    lk = getattr(t, "_vg_bwdstat", None)
+    if lk is not None:
+        lk.armed = True
+
+
+def claim_bwdstat(t):
+    """Called by a convolution on its input tensor: the producer BatchNorm's link, if it is armed."""
+    lk = getattr(t, "_vg_bwdstat", None)
+    if lk is None or not lk.armed:
+        return None
+    lk.claims += 1
+    return lk
+
+
+def _dgrad_with_bnstats(prod, final: bool, dtype) -> bool:
+    return (prod is not None and final and prod.claims == 1 and prod.x is not None and dtype == torch.bfloat16
+            and prod.act in (L.ACT_NONE, L.ACT_LRELU) and not _os.environ.get("VG_NO_BNSTAT_FUSION"))
+
+
+def _bn_bwd_stats_struct(prod, sums):
+    vec = prod.vec
+    return L.BnBwdStats(x=prod.x.data_ptr(), y=L.ptr(prod.y), mean=vec[0].data_ptr(), invstd=vec[1].data_ptr(),
+                        scale=vec[2].data_ptr(), shift=vec[3].data_ptr(), sums=sums.data_ptr(), cpad=prod.cpad, act=prod.act)
+
+
 def _bias_done(link) -> bool:
     if link is None or not link.done:
         return False
@@ -379,10 +420,10 @@ class Conv2dFn(torch.autograd.Function):
     """y = act(conv2d(x, W) + b) on NHWC tensors; optionally emits BatchNorm statistics."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None, reslink=None):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None, reslink=None, prod=None):
         _require_cuda(x, "conv2d")
         ctx.set_materialize_grads(False)    # else autograd zero-fills a gradient for the (non-differentiable) statistics
-        ctx.link, ctx.reslink = link, reslink
+        ctx.link, ctx.reslink, ctx.prod = link, reslink, prod
         x = x.contiguous()
         n, h, w, xcs = x.shape
         co, ci, k, _ = weight.shape
@@ -407,7 +448,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gstats):
         if gy is None:
-            return (None,) * 10
+            return (None,) * 11
         x, weight, y = ctx.saved_tensors
         d, lib = ctx.d, L.load()
         gy = gy.contiguous()
@@ -422,25 +463,37 @@ class Conv2dFn(torch.autograd.Function):
                 dx = parked
             else:
                 dx = torch.empty_like(x)
-            L.check(_timed(None, _conv_flops(d),
-                           lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
-                                                     L.ACT_NONE, int(parked is not None), L.stream()),
-                           _shape_tag("dgrad", d)), "conv_dgrad")
+            prod = ctx.prod
+            # dx is the complete gradient of x unless a ResidualBlock skip gradient is still on its way through autograd
+            if _dgrad_with_bnstats(prod, ctx.reslink is None or parked is not None, x.dtype):
+                sums = _zeros_f64(L.STATS_REPLICAS * 2 * prod.cpad + 2 * prod.cpad, x.device)
+                bs, fused = _bn_bwd_stats_struct(prod, sums), C.c_int(0)
+                L.check(_timed(None, _conv_flops(d),
+                               lambda: lib.vg_conv_dgrad_bnstats(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx.data_ptr(),
+                                                                 int(parked is not None), C.byref(bs), C.byref(fused), L.stream()),
+                               _shape_tag("dgrad", d)), "conv_dgrad_bnstats")
+                if fused.value:
+                    prod.sums, prod.fused = sums, True
+            else:
+                L.check(_timed(None, _conv_flops(d),
+                               lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
+                                                         L.ACT_NONE, int(parked is not None), L.stream()),
+                               _shape_tag("dgrad", d)), "conv_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, x, gy, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2] and not _bias_done(ctx.link):
             db = _channel_sum(gy, d.co, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
     """y = act(conv_transpose2d(x, W) + b): the dgrad kernel of the conv object W[O=in][I=out]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None):
+    def forward(ctx, x, weight, bias, stride, pad, act, want_stats, packs, link=None, prod=None):
         _require_cuda(x, "conv_transpose2d")
         ctx.set_materialize_grads(False)
-        ctx.link = link
+        ctx.link, ctx.prod = link, prod
         x = x.contiguous()
         n, h, w, xcs = x.shape
         cin_t, cout_t, k, _ = weight.shape
@@ -468,7 +521,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gstats):
         if gy is None:
-            return (None,) * 9
+            return (None,) * 10
         x, weight, y = ctx.saved_tensors
         d, lib = ctx.d, L.load()
         gy = gy.contiguous()
@@ -478,14 +531,25 @@ class ConvTranspose2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wp = ctx.packs.get(weight, d, 0, x.dtype)
             dx = torch.empty_like(x)
-            L.check(_timed(None, _conv_flops(d),
-                           lambda: lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None,
-                                                   L.ACT_NONE, 0, L.stream()), _shape_tag("convT_dgrad", d)), "convT_dgrad")
+            prod = ctx.prod
+            if _dgrad_with_bnstats(prod, True, x.dtype):
+                sums = _zeros_f64(L.STATS_REPLICAS * 2 * prod.cpad + 2 * prod.cpad, x.device)
+                bs, fused = _bn_bwd_stats_struct(prod, sums), C.c_int(0)
+                L.check(_timed(None, _conv_flops(d),
+                               lambda: lib.vg_conv_fwd_bnstats(C.byref(d), gy.data_ptr(), wp.data_ptr(), dx.data_ptr(), 0,
+                                                               C.byref(bs), C.byref(fused), L.stream()),
+                               _shape_tag("convT_dgrad", d)), "convT_dgrad_bnstats")
+                if fused.value:
+                    prod.sums, prod.fused = sums, True
+            else:
+                L.check(_timed(None, _conv_flops(d),
+                               lambda: lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None,
+                                                       L.ACT_NONE, 0, L.stream()), _shape_tag("convT_dgrad", d)), "convT_dgrad")
         if ctx.needs_input_grad[1]:
             dw = _wgrad(d, gy, x, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2] and not _bias_done(ctx.link):
             db = _channel_sum(gy, d.ci, ctx.bparam)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -531,7 +595,8 @@ class BNActFn(torch.autograd.Function):
     """y = act(batchnorm_train(x) (+ res)); statistics come from the producing conv's epilogue."""
 
     @staticmethod
-    def forward(ctx, x, stats, gamma, beta, res, running_mean, running_var, nbt, eps, momentum, act, c, link=None, reslink=None):
+    def forward(ctx, x, stats, gamma, beta, res, running_mean, running_var, nbt, eps, momentum, act, c, link=None, reslink=None,
+                bslink=None):
         lib = L.load()
         x = x.contiguous()
         cs = x.shape[-1]
@@ -554,6 +619,10 @@ class BNActFn(torch.autograd.Function):
                                   act, L.vg_dtype(x.dtype), L.stream()), "bn_act_fwd")
         ctx.c, ctx.cpad, ctx.act, ctx.has_res = c, cpad, act, res is not None
         ctx.gparam, ctx.bparam, ctx.link, ctx.reslink = gamma, beta, link, reslink
+        ctx.bslink = bslink
+        if bslink is not None:      # what the consumer's input-gradient launch needs to take this layer's backward sums
+            bslink.x, bslink.vec, bslink.c, bslink.cpad, bslink.act = x, vec, c, cpad, act
+            bslink.y = y if (res is not None or act not in (L.ACT_NONE, L.ACT_LRELU)) else None
         ctx.save_for_backward(x, y, vec, gamma)
         return y
 
@@ -565,13 +634,19 @@ class BNActFn(torch.autograd.Function):
         cs = x.shape[-1]
         rows = x.numel() // cs
         c, cpad = ctx.c, ctx.cpad
-        sums = _zeros_f64(L.STATS_REPLICAS * 2 * cpad + 2 * cpad, x.device)
         dtc = L.vg_dtype(x.dtype)
         # without a residual the LeakyReLU mask is recomputed from x (one tensor read less per pass)
         yp = None if (not ctx.has_res and ctx.act in (L.ACT_NONE, L.ACT_LRELU)) else y.data_ptr()
-        L.check(lib.vg_bn_bwd_reduce(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
-                                     vec[2].data_ptr(), vec[3].data_ptr(), sums.data_ptr(), rows, cs, c, cpad, ctx.act, dtc,
-                                     L.stream()), "bn_bwd_reduce")
+        bsl = ctx.bslink
+        if bsl is not None and bsl.fused:       # the consumer's input-gradient launch already took the sums (BwdStatLink)
+            sums = bsl.sums
+        else:
+            sums = _zeros_f64(L.STATS_REPLICAS * 2 * cpad + 2 * cpad, x.device)
+            L.check(lib.vg_bn_bwd_reduce(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
+                                         vec[2].data_ptr(), vec[3].data_ptr(), sums.data_ptr(), rows, cs, c, cpad, ctx.act, dtc,
+                                         L.stream()), "bn_bwd_reduce")
+        if bsl is not None:
+            bsl.x = bsl.y = bsl.vec = bsl.sums = None
         sync = ctx.sync
         if sync is not None:
             sync.sum_(sums[:L.STATS_REPLICAS * 2 * cpad])
@@ -594,8 +669,8 @@ class BNActFn(torch.autograd.Function):
         if dres is not None and ctx.reslink is not None and _STEP[0] and ctx.needs_input_grad[4]:
             ctx.reslink.dres, dres = dres, None      # picked up by the block's first conv (see ResLink)
         if direct:
-            return dx, None, None, None, dres, None, None, None, None, None, None, None, None, None
-        return dx, None, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None, None
+            return dx, None, None, None, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, None, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None, None, None
 
 
 def bn_eval_act(x: torch.Tensor, gamma, beta, running_mean, running_var, eps: float, act: int, c: int,
