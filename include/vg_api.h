@@ -121,6 +121,23 @@ size_t vg_conv_wgrad_ws_bytes(const vg_conv_desc* d);
 int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, int accumulate,
                   void* stream);
 
+/* ---- thin layers: convolutions with a 3-channel side, bf16 (csrc/thin.hip) --------------------
+ * The image-side convolutions of every model (first conv of the encoders and discriminators, e.g.
+ * vq_vae_gan/model.py:146 and :211; last conv of the decoders, :193) and their gradients.  The 3-channel tensor is
+ * NHWC with a channel stride of FOUR (8 bytes per pixel, channel 3 zero): desc.xcs == 4 (thin input) or desc.ycs == 4
+ * (thin output); the other side has <= 64 channels at stride 64.  The master OIHW f32 weights are read directly (no
+ * packed image).  vg_thin_conv_supported: 0 = not a thin layer (use the vg_conv_* entry points on 32-padded tensors),
+ * 1 = thin input (3x3 stride 1 pad 1, or 4x4 stride 2 pad 1), 2 = thin output (3x3 stride 1 pad 1).
+ * ws (forward, input gradient): vg_thin_conv_ws_bytes() bytes of scratch for the bf16 weight image of the launch. */
+int vg_thin_conv_supported(const vg_conv_desc* d);
+size_t vg_thin_conv_ws_bytes(void);
+int vg_thin_conv_fwd(const vg_conv_desc* d, const void* x, const float* w_oihw, const float* bias, void* y, double* stats,
+                     int act, void* ws, void* stream);
+int vg_thin_conv_dgrad(const vg_conv_desc* d, const void* dy, const float* w_oihw, void* dx, void* ws, void* stream);
+size_t vg_thin_conv_wgrad_ws_bytes(const vg_conv_desc* d);
+int vg_thin_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, int accumulate,
+                       void* stream);
+
 /* per-channel column sum: out[c] (f32) = sum_m a[m][c], c < c_valid.  bias gradients.
  * ws: VG_STATS_REPLICAS*cs f64 of scratch.  accumulate != 0: out[c] +=. */
 int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws, int accumulate,

@@ -186,8 +186,35 @@ template <typename T> __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel
   }
 }
 
+// 4-channel bf16 NHWC (the thin image-side layout, csrc/thin.hip): a thread owns one pixel, plane reads and 8-byte
+// pixel writes are both coalesced.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int C, long HW) {
+  const long pix = blockIdx.x * 256L + threadIdx.x;
+  if (pix >= HW) return;
+  const int n = blockIdx.y;
+  bf16x4 o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) o[c] = (bf16_t)(c < C ? src[((size_t)n * C + c) * HW + pix] : 0.f);
+  *(bf16x4*)(dst + ((size_t)n * HW + pix) * 4) = o;
+}
+__global__ __launch_bounds__(256) void nhwc4_to_nchw_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int C, long HW) {
+  const long pix = blockIdx.x * 256L + threadIdx.x;
+  if (pix >= HW) return;
+  const int n = blockIdx.y;
+  const bf16x4 v = *(const bf16x4*)(src + ((size_t)n * HW + pix) * 4);
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (c < C) dst[((size_t)n * C + c) * HW + pix] = (float)v[c];
+}
+
 extern "C" int vg_nchw_to_nhwc(const float* src, void* dst, int n, int c, int h, int w, int cs, int dtype, void* stream) {
   VG_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && cs >= c, "nchw_to_nhwc: bad arguments");
+  if (dtype == VG_BF16 && cs == 4) {
+    const long hw = (long)h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((unsigned)vg_ceil_div(hw, 256), n), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, hw);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   dim3 grid((unsigned)vg_ceil_div((int64_t)h * w, 64), (unsigned)vg_ceil_div(cs, 32), n);
   if (dtype == VG_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, c, h * w, cs);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src, (float*)dst, c, h * w, cs);
@@ -197,6 +224,12 @@ extern "C" int vg_nchw_to_nhwc(const float* src, void* dst, int n, int c, int h,
 
 extern "C" int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h, int w, int cs, int dtype, void* stream) {
   VG_REQUIRE(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && cs >= c, "nhwc_to_nchw: bad arguments");
+  if (dtype == VG_BF16 && cs == 4) {
+    const long hw = (long)h * w;
+    hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3((unsigned)vg_ceil_div(hw, 256), n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, c, hw);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   dim3 grid((unsigned)vg_ceil_div((int64_t)h * w, 64), (unsigned)vg_ceil_div(c, 32), n);
   if (dtype == VG_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, c, h * w, cs);
   else hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, c, h * w, cs);
@@ -254,9 +287,48 @@ __global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ d
   dst[i] = accumulate ? dst[i] + (float)(t * scale) : (float)(t * scale);
 }
 
+// 4-channel bf16 rows (the thin image-side layout): a thread walks pixels, 8-byte loads
+__global__ __launch_bounds__(256) void channel_sum4_kernel(const bf16_t* __restrict__ a, int64_t rows, double* __restrict__ ws) {
+  __shared__ float red[4][4];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  double dacc[4] = {0.0, 0.0, 0.0, 0.0};
+  int cnt = 0;
+  for (int64_t r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const bf16x4 v = *(const bf16x4*)(a + r * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += (float)v[e];
+    if (++cnt == 64) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dacc[e] += acc[e]; acc[e] = 0.f; }
+      cnt = 0;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float t = wave_sum((float)(dacc[e] + (double)acc[e]));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int e = threadIdx.x;
+    unsafeAtomicAdd(&ws[(size_t)(blockIdx.x % VG_STATS_REPLICAS) * 4 + e], (double)((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])));
+  }
+}
+
 extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws,
                               int accumulate, void* stream) {
   VG_REQUIRE(a && out && ws && rows > 0 && cs > 0 && c_valid <= cs, "channel_sum: bad arguments");
+  if (dtype == VG_BF16 && cs == 4) {
+    hipStream_t st4 = (hipStream_t)stream;
+    VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 4 * VG_STATS_REPLICAS, st4));
+    int blocks = (int)vg_ceil_div(rows, 256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(channel_sum4_kernel, dim3(blocks), dim3(256), 0, st4, (const bf16_t*)a, rows, ws);
+    VG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, st4, (const double*)ws, out, c_valid, 1.0, VG_STATS_REPLICAS, 4, accumulate);
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_sum: channel stride %d unsupported", cs);
   hipStream_t st = (hipStream_t)stream;

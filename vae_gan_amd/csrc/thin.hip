@@ -1,0 +1,558 @@
+// Thin layers: convolutions with a 3-channel side (the image-side tensors: encoder / discriminator inputs, decoder
+// output and their gradients), bf16.
+//
+// As ordinary gather-GEMMs these layers pad 3 channels to one 64-byte K chunk (32 channels): ~0.1 % of the step's
+// FLOPs took 2.8 ms of a 44 ms step, and the image tensors were 10x their payload in HBM.  Here the 3-channel tensor
+// is NHWC with FOUR channels (8 bytes per pixel, channel 3 = 0) and the taps go into the GEMM dimension that would
+// otherwise be padding:
+//   * thin -> wide  (conv 3->64: forward; input gradient of 64->3): K = (r, s, c) = 4x4x4 = 64, one im2col row per
+//     pixel read straight out of the 8-byte-pixel halo in LDS;
+//   * wide -> thin  (conv 64->3: forward; input gradient of 3->64, stride 1 and the stride-2 transposed gather):
+//     N = (r, s, c): P[q][(r,s,c)] = sum_n in[q][n] W[..] is a plain 1x1 GEMM over the input tile, then a col2im
+//     gather-sum over the taps in LDS;
+//   * weight gradient: dW[n][(r,s,c)] = sum over pixels, K = pixels, both operands transposed into LDS.
+// All three read the master OIHW f32 weights themselves (a few thousand values): no packed weight images.
+// Every kernel is bound by the one pass over the 64-channel tensor it touches (HBM).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+struct ThinParams {
+  const bf16_t* thin;   // [N][TH_][TW_][4]
+  const bf16_t* wide;   // [N][WH][WW][Ws]
+  bf16_t* out;          // the tensor being written (thin or wide)
+  const float* w;       // master weight [O][I][R][R]
+  const float* bias;
+  double* stats;        // thin->wide forward: [VG_STATS_REPLICAS][2][cpad]
+  float* part;          // weight gradient: [blocks][64][64] partial images
+  const bf16_t* wpk;    // packed [64][72] weight image (thin_pack_kernel)
+  int N, TH_, TW_, WH, WW, Ws;
+  int O, I, R, stride, pad;   // pad: of the thin-side gather (see each kernel)
+  int wmode, nw, nt, act, cpad;
+  int tilesX, tilesY, ntiles;
+};
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// The [64][72] bf16 weight image a block keeps in LDS (rows of 144 bytes: conflict-free 16-byte fragment reads),
+// made once per launch from the master OIHW f32 weights by one small block; the compute blocks copy it with 16-byte
+// loads.  (Filled by every block straight from the f32 master, the 16 dependent scattered loads per thread cost more
+// than the block's whole MFMA work.)
+//   wide_out = 1 (thin_in_kernel): row n, column k = (r*4+s)*4+c:  wmode 0: W[n][c][r][s]; 1: W[c][n][R-1-r][R-1-s]
+//   wide_out = 0 (thin_out_kernel): row (r*R+s)*4+c, column n:     wmode 0: W[c][n][r][s]; 1: W[n][c][R-1-r][R-1-s]; 2: W[n][c][r][s]
+__global__ __launch_bounds__(256) void thin_pack_kernel(const ThinParams p, bf16_t* __restrict__ wpk, int wide_out) {
+  const int R = p.R;
+  for (int idx = threadIdx.x; idx < 64 * 72; idx += 256) {
+    const int row = idx / 72, col = idx - row * 72;
+    float v = 0.f;
+    if (col < 64) {
+      if (wide_out) {
+        const int n = row, r = col >> 4, s = (col >> 2) & 3, c = col & 3;
+        if (r < R && s < R && c < p.nt && n < p.nw)
+          v = p.wmode == 0 ? p.w[(((size_t)n * p.I + c) * R + r) * R + s]
+                           : p.w[(((size_t)c * p.I + n) * R + (R - 1 - r)) * R + (R - 1 - s)];
+      } else {
+        const int n = col, tap = row >> 2, c = row & 3, r = tap / R, s = tap - r * R;
+        if (row < R * R * 4 && c < p.nt && n < p.nw) {
+          if (p.wmode == 0) v = p.w[(((size_t)c * p.I + n) * R + r) * R + s];
+          else if (p.wmode == 1) v = p.w[(((size_t)n * p.I + c) * R + (R - 1 - r)) * R + (R - 1 - s)];
+          else v = p.w[(((size_t)n * p.I + c) * R + r) * R + s];
+        }
+      }
+    }
+    wpk[idx] = (bf16_t)v;
+  }
+}
+__device__ __forceinline__ void thin_load_weights(bf16_t* wl, const bf16_t* __restrict__ wpk, int tid) {
+  for (int q = tid; q < 64 * 72 / 8; q += 256) *(u32x4*)(wl + q * 8) = *(const u32x4*)(wpk + q * 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin -> wide.  out[pix][n] = sum_{r,s,c} thin[pix*ST - pad + (r,s)][c] * Wk[n][r][s][c],  k = (r*4 + s)*4 + c.
+// wmode 0: Wk[n][r][s][c] = W[n][c][r][s] (forward of a thin-input conv); 1: Wk[n][r][s][c] = W[c][n][R-1-r][R-1-s]
+// (input gradient of a thin-output conv).  Block = 4 waves over an 8 x 32 output tile; a wave owns two tile rows.
+// ---------------------------------------------------------------------------------------------
+template <int R, int ST>
+__global__ __launch_bounds__(256) void thin_in_kernel(const ThinParams p) {
+  constexpr int TH = 8, TW = 32, HH = (TH - 1) * ST + R, HW = (TW - 1) * ST + R, HWP = HW + (HW & 1) + 2;
+  __shared__ u32x2 halo[HH * HWP];
+  __shared__ __attribute__((aligned(16))) bf16_t wl[64 * 72];
+  __shared__ __attribute__((aligned(16))) bf16_t stg[4][32 * 64];
+  __shared__ float red[4][64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+  const int tpi = p.tilesX * p.tilesY;
+  const int img = blockIdx.x / tpi, trem = blockIdx.x - img * tpi;
+  const int ty0 = (trem / p.tilesX) * TH, tx0 = (trem % p.tilesX) * TW;
+
+  const u32x2* __restrict__ tg = (const u32x2*)p.thin;
+  for (int idx = tid; idx < HH * HWP; idx += 256) {
+    const int hy = idx / HWP, hx = idx - hy * HWP;
+    const int iy = ty0 * ST - p.pad + hy, ix = tx0 * ST - p.pad + hx;
+    u32x2 v = {0u, 0u};
+    if ((unsigned)iy < (unsigned)p.TH_ && (unsigned)ix < (unsigned)p.TW_) v = tg[((size_t)img * p.TH_ + iy) * p.TW_ + ix];
+    halo[idx] = v;
+  }
+  thin_load_weights(wl, p.wpk, tid);
+  __syncthreads();
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {                       // k step j = kernel row j: k = 16 j + 8 h + (0..7) = (r = j, s = 2h, 2h+1)
+    u32x4 fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int base = ((2 * wave + i) * ST + j) * HWP + l32 * ST + 2 * h;
+      const u32x2 lo = halo[base], hi = halo[base + 1];
+      fa[i] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) fb[jj] = *(const u32x4*)(wl + (jj * 32 + l32) * 72 + 16 * j + 8 * h);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) acc[i][jj] = mfma16(fa[i], fb[jj], acc[i][jj]);
+  }
+
+  // ---- epilogue: bias, BatchNorm statistics of the bf16-rounded pre-activation, activation; one 32-pixel tile row at a
+  // time is transposed through a 4 KB per-wave LDS tile and leaves as 16-byte stores
+  bf16_t* wt = stg[wave];          // [32 px][64 ch]
+  float bv[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) bv[jj] = (p.bias != nullptr && jj * 32 + l32 < p.nw) ? p.bias[jj * 32 + l32] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oy = ty0 + 2 * wave + i;
+    const bool rowok = oy < p.WH;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int n = jj * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[i][jj][r] + bv[jj];
+        v = (float)(bf16_t)v;
+        if (rowok && tx0 + col < p.WW) { s1[jj] += v; s2[jj] += v * v; }
+        if (p.act == VG_ACT_LRELU) v = vg_lrelu(v);
+        else if (p.act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
+        if (n >= p.nw) v = 0.f;
+        wt[col * 64 + n] = (bf16_t)v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (rowok) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = lane + 64 * u;
+        const int px = q >> 3, pc = q & 7;
+        if (tx0 + px < p.WW)
+          *(u32x4*)(p.out + (((size_t)img * p.WH + oy) * p.WW + tx0 + px) * p.Ws + pc * 8) = *(const u32x4*)(wt + px * 64 + pc * 8);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (p.stats != nullptr) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const float t1 = s1[jj] + __shfl_xor(s1[jj], 32, 64), t2 = s2[jj] + __shfl_xor(s2[jj], 32, 64);
+      if (h == 0) { red[wave][jj * 32 + l32][0] = t1; red[wave][jj * 32 + l32][1] = t2; }
+    }
+    __syncthreads();
+    if (tid < 64 && tid < p.nw) {
+      const float t1 = (red[0][tid][0] + red[1][tid][0]) + (red[2][tid][0] + red[3][tid][0]);
+      const float t2 = (red[0][tid][1] + red[1][tid][1]) + (red[2][tid][1] + red[3][tid][1]);
+      const int rep = blockIdx.x % VG_STATS_REPLICAS;
+      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.cpad + tid], (double)t1);
+      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.cpad + tid], (double)t2);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wide -> thin.  P[q][(r,s,c)] = sum_n wide[q][n] * Wl[(r,s,c)][n] over the input tile (6 x 34 pixels), then
+//   ST = 1: out[pix][c] = sum_{r,s} P[pix - pad + (r,s)][(r,s,c)]          (R x R gather, output tile 4 x 32)
+//   ST = 2: out[Y][X][c] = sum_{r,s: Y+1-r, X+1-s even} P[((Y+1-r)/2, (X+1-s)/2)][(r,s,c)]   (transposed 4x4 stride 2
+//           pad 1, output tile 8 x 64 over the 4 x 32 input tile + 1 halo)
+// Wl by wmode: 0: W[c][n][r][s] (forward of a thin-output conv); 1: W[n][c][R-1-r][R-1-s] (input gradient of a
+// thin-input stride-1 conv, pad = R-1-conv pad); 2: W[n][c][r][s] (ST = 2).
+// ---------------------------------------------------------------------------------------------
+template <int R, int ST>
+__global__ __launch_bounds__(256) void thin_out_kernel(const ThinParams p) {
+  constexpr int IH = 6, IW = 34, M = IH * IW, MB = (M + 31) / 32, NC = R * R * 4, PW = NC + 4, NLD = MB * 32 * 8 / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  bf16_t* at = (bf16_t*)tsm;                     // [MB*32][72]
+  bf16_t* wl = at + MB * 32 * 72;                // [64][72]
+  float* P = (float*)(wl + 64 * 72);             // [M][PW], rows 16-byte aligned
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+  const int tpi = p.tilesX * p.tilesY;
+  thin_load_weights(wl, p.wpk, tid);
+  float bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bv[c] = (p.bias != nullptr && c < p.nt) ? p.bias[c] : 0.f;
+  u32x2* __restrict__ og = (u32x2*)p.out;
+
+  // a block walks tiles; the wide input tile of the NEXT tile is requested into registers before the current one is
+  // computed, so its HBM latency runs under the MFMA / col2im work (one tile per block was latency-bound: 2 blocks per CU)
+  u32x4 nxt[NLD];
+  auto request = [&](int tile) {
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int iy0 = (trem / p.tilesX) * 4 - (ST == 1 ? p.pad : 1), ix0 = (trem % p.tilesX) * 32 - (ST == 1 ? p.pad : 1);
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 256 * u;
+      const int q = idx >> 3, pc = idx & 7;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < M) {
+        const int hy = q / IW, hx = q - hy * IW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if ((unsigned)iy < (unsigned)p.WH && (unsigned)ix < (unsigned)p.WW && pc * 8 < p.Ws)
+          v = *(const u32x4*)(p.wide + (((size_t)img * p.WH + iy) * p.WW + ix) * p.Ws + pc * 8);
+      }
+      nxt[u] = v;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) request(tile);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int ty0 = (trem / p.tilesX) * 4, tx0 = (trem % p.tilesX) * 32;      // core tile origin on the WIDE grid
+    const int iy0 = ty0 - (ST == 1 ? p.pad : 1), ix0 = tx0 - (ST == 1 ? p.pad : 1);
+    __syncthreads();                               // the previous tile's fragments and P have been read
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 256 * u;
+      *(u32x4*)(at + (idx >> 3) * 72 + (idx & 7) * 8) = nxt[u];
+    }
+    if (tile + (int)gridDim.x < p.ntiles) request(tile + gridDim.x);
+    __syncthreads();
+    for (int mb = wave; mb < MB; mb += 4) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 fa = *(const u32x4*)(at + (mb * 32 + l32) * 72 + 16 * j + 8 * h);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          if (jj * 32 < NC) {
+            const u32x4 fb = *(const u32x4*)(wl + (jj * 32 + l32) * 72 + 16 * j + 8 * h);
+            acc[jj] = mfma16(fa, fb, acc[jj]);
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int col = jj * 32 + l32;
+        if (col < NC) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int q = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (q < M) P[q * PW + col] = acc[jj][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    auto finish = [&](f32x4 v, int Y, int X) {
+      bf16x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float f = (float)(bf16_t)(v[c] + bv[c]);
+        if (p.act == VG_ACT_LRELU) f = vg_lrelu(f);
+        else if (p.act == VG_ACT_SIGMOID) f = vg_sigmoid(f);
+        if (c >= p.nt) f = 0.f;
+        o[c] = (bf16_t)f;
+      }
+      og[((size_t)img * p.TH_ + Y) * p.TW_ + X] = __builtin_bit_cast(u32x2, o);
+    };
+    if constexpr (ST == 1) {
+      if (tid < 128) {                              // one output pixel per thread: 9 16-byte reads of P
+        const int oy = tid >> 5, ox = tid & 31;
+        const int Y = ty0 + oy, X = tx0 + ox;
+        if (Y < p.TH_ && X < p.TW_) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int s = 0; s < R; ++s) v += *(const f32x4*)(P + ((oy + r) * IW + ox + s) * PW + (r * R + s) * 4);
+          finish(v, Y, X);
+        }
+      }
+    } else {
+      for (int o = tid; o < 8 * 64; o += 256) {
+        const int oy = o >> 6, ox = o & 63;
+        const int Y = 2 * ty0 + oy, X = 2 * tx0 + ox;
+        if (Y >= p.TH_ || X >= p.TW_) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const int r0 = (Y + 1) & 1, s0 = (X + 1) & 1;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int r = r0 + 2 * a, s = s0 + 2 * b;
+            const int qy = (Y + 1 - r) / 2 - iy0, qx = (X + 1 - s) / 2 - ix0;      // inside the 6 x 34 tile by construction
+            v += *(const f32x4*)(P + (qy * IW + qx) * PW + (r * R + s) * 4);
+          }
+        finish(v, Y, X);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient.  acc[n][(r,s,c)] = sum_q wide[q][n] * thin[q*ST - pad + (r,s)][c] over all pixels q of the wide
+// tensor: K = pixels.  Persistent blocks walk 8 x 32 pixel tiles; both operands are written TRANSPOSED into LDS
+// ([channel][pixel], conflict-free 2-byte writes: a lane owns one pixel) so that a fragment is 8 consecutive pixels.
+// Every block writes one 64 x 64 partial image; thin_wgrad_finish sums them in a fixed order into OIHW.
+// ---------------------------------------------------------------------------------------------
+template <int R, int ST>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p) {
+  constexpr int TH = 8, TW = 32, HH = (TH - 1) * ST + R, HW = (TW - 1) * ST + R, HWP = HW + (HW & 1) + 2, RS = 264;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  bf16_t* wT = (bf16_t*)tsm;                     // [64][RS]
+  bf16_t* cT = wT + 64 * RS;                     // [64][RS]
+  u32x2* halo = (u32x2*)(cT + 64 * RS);          // [HH][HWP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+  const int tpi = p.tilesX * p.tilesY;
+  const u32x2* __restrict__ tg = (const u32x2*)p.thin;
+  for (int idx = tid; idx < 64 * RS; idx += 256) cT[idx] = (bf16_t)0.f;      // rows of taps outside R x R stay zero
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int mblk = wave >> 1, nblk = wave & 1;
+  const int py = tid >> 5, px = tid & 31;
+  // the NEXT tile's pixels are requested into registers before the current tile is computed (HBM latency under the
+  // transposes and MFMAs; single-buffered with 2 blocks per CU the loop was latency-bound)
+  constexpr int NH = (HH * HWP + 255) / 256;
+  u32x4 nw_[8];
+  u32x2 nh_[NH];
+  auto request = [&](int tile) {
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int ty0 = (trem / p.tilesX) * TH, tx0 = (trem % p.tilesX) * TW;
+#pragma unroll
+    for (int u = 0; u < NH; ++u) {
+      const int idx = tid + 256 * u;
+      const int hy = idx / HWP, hx = idx - hy * HWP;
+      const int iy = ty0 * ST - p.pad + hy, ix = tx0 * ST - p.pad + hx;
+      u32x2 v = {0u, 0u};
+      if (idx < HH * HWP && (unsigned)iy < (unsigned)p.TH_ && (unsigned)ix < (unsigned)p.TW_) v = tg[((size_t)img * p.TH_ + iy) * p.TW_ + ix];
+      nh_[u] = v;
+    }
+    const int qy = ty0 + py, qx = tx0 + px;
+    const bool ok = qy < p.WH && qx < p.WW;
+    const bf16_t* src = p.wide + (((size_t)img * p.WH + qy) * p.WW + qx) * p.Ws;
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok && pc * 8 < p.Ws) v = *(const u32x4*)(src + pc * 8);
+      nw_[pc] = v;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) request(tile);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    __syncthreads();                                   // the previous tile's fragments have been read
+#pragma unroll
+    for (int u = 0; u < NH; ++u)
+      if (tid + 256 * u < HH * HWP) halo[tid + 256 * u] = nh_[u];
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) {
+      const bf16x8 e = __builtin_bit_cast(bf16x8, nw_[pc]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) wT[(pc * 8 + k) * RS + tid] = e[k];
+    }
+    if (tile + (int)gridDim.x < p.ntiles) request(tile + gridDim.x);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int s = 0; s < R; ++s) {
+        const bf16x4 e = __builtin_bit_cast(bf16x4, halo[(py * ST + r) * HWP + px * ST + s]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cT[((r * 4 + s) * 4 + c) * RS + tid] = e[c];
+      }
+    __syncthreads();
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const u32x4 fa = *(const u32x4*)(wT + (mblk * 32 + l32) * RS + ks * 16 + 8 * h);
+      const u32x4 fb = *(const u32x4*)(cT + (nblk * 32 + l32) * RS + ks * 16 + 8 * h);
+      acc = mfma16(fa, fb, acc);
+    }
+  }
+  float* __restrict__ part = p.part + (size_t)blockIdx.x * 4096;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[(mblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + nblk * 32 + l32] = acc[r];
+}
+
+// dW[o][i][r][s] (+)= sum over the partial images, fixed order.  wmode 0: acc[n = o][(r,s,c = i)]; 1: acc[n = i][(R-1-r, R-1-s, c = o)]
+__global__ __launch_bounds__(64) void thin_wgrad_finish_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw,
+                                                               int O, int I, int R, int wmode, int accumulate) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= O * I * R * R) return;
+  const int s = t % R, r = (t / R) % R, i = (t / (R * R)) % I, o = t / (R * R * I);
+  const int idx = wmode == 0 ? o * 64 + (r * 4 + s) * 4 + i : i * 64 + ((R - 1 - r) * 4 + (R - 1 - s)) * 4 + o;
+  float v = 0.f;
+  int b = 0;
+  for (; b + 8 <= nparts; b += 8) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = part[(size_t)(b + u) * 4096 + idx];
+    v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  for (; b < nparts; ++b) v += part[(size_t)b * 4096 + idx];
+  dw[t] = accumulate ? dw[t] + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// 0: not a thin layer; 1: thin INPUT (ci <= 3 on a 4-channel NHWC tensor, <= 64 output channels on a 64-stride
+// tensor; 3x3 stride 1 pad 1, or 4x4 stride 2 pad 1); 2: thin OUTPUT (co <= 3, <= 64 input channels; 3x3 stride 1 pad 1)
+extern "C" int vg_thin_conv_supported(const vg_conv_desc* d) {
+  if (!d || d->dtype != VG_BF16 || d->r != d->s || d->n <= 0) return 0;
+  const bool k3 = d->r == 3 && d->stride == 1 && d->pad == 1;
+  const bool k4 = d->r == 4 && d->stride == 2 && d->pad == 1 && d->h % 2 == 0 && d->w % 2 == 0;
+  if (d->ci <= 3 && d->xcs == 4 && d->co <= 64 && d->ycs == 64 && (k3 || k4)) return 1;
+  if (d->co <= 3 && d->ycs == 4 && d->ci <= 64 && d->xcs == 64 && k3) return 2;
+  return 0;
+}
+
+static void thin_fill(const vg_conv_desc* d, int kind, ThinParams& p) {
+  memset(&p, 0, sizeof(p));
+  p.N = d->n; p.O = d->co; p.I = d->ci; p.R = d->r; p.stride = d->stride; p.Ws = 64;
+  if (kind == 1) { p.TH_ = d->h; p.TW_ = d->w; p.WH = d->oh; p.WW = d->ow; p.nw = d->co; p.nt = d->ci; }
+  else { p.TH_ = d->oh; p.TW_ = d->ow; p.WH = d->h; p.WW = d->w; p.nw = d->ci; p.nt = d->co; }
+}
+template <int R> static constexpr int thin_out_lds() { return (7 * 32 * 72 + 64 * 72) * 2 + 6 * 34 * (R * R * 4 + 4) * 4; }
+template <int R, int ST> static constexpr int thin_wgrad_lds() {
+  return 2 * 64 * 264 * 2 + ((8 - 1) * ST + R) * ((32 - 1) * ST + R + (((32 - 1) * ST + R) & 1) + 2) * 8;
+}
+template <typename K> static int thin_lds_attr(K kern, int bytes) {
+  VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return VG_OK;
+}
+static void thin_tiles(ThinParams& p, int gh, int gw, int th, int tw) {
+  p.tilesX = (int)vg_ceil_div(gw, tw); p.tilesY = (int)vg_ceil_div(gh, th);
+  p.ntiles = p.N * p.tilesX * p.tilesY;
+}
+
+extern "C" size_t vg_thin_conv_ws_bytes(void) { return 64 * 72 * sizeof(bf16_t); }
+
+static int thin_out_blocks(const ThinParams& p) { return p.ntiles < 512 ? p.ntiles : 512; }      // 2 resident blocks per CU
+
+extern "C" int vg_thin_conv_fwd(const vg_conv_desc* d, const void* x, const float* w_oihw, const float* bias, void* y,
+                                double* stats, int act, void* ws, void* stream) {
+  const int kind = vg_thin_conv_supported(d);
+  VG_REQUIRE(kind != 0, "thin_conv_fwd: not a supported thin layer");
+  VG_REQUIRE(x && w_oihw && y && ws, "thin_conv_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  ThinParams p;
+  thin_fill(d, kind, p);
+  p.w = w_oihw; p.bias = bias; p.act = act; p.wmode = 0; p.pad = d->pad; p.out = (bf16_t*)y; p.wpk = (const bf16_t*)ws;
+  hipLaunchKernelGGL(thin_pack_kernel, dim3(1), dim3(256), 0, st, p, (bf16_t*)ws, kind == 1 ? 1 : 0);
+  VG_LAUNCH_CHECK();
+  if (kind == 1) {
+    p.thin = (const bf16_t*)x; p.stats = stats; p.cpad = d->co <= 32 ? 32 : 64;
+    thin_tiles(p, p.WH, p.WW, 8, 32);
+    if (d->r == 3) hipLaunchKernelGGL((thin_in_kernel<3, 1>), dim3(p.ntiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((thin_in_kernel<4, 2>), dim3(p.ntiles), dim3(256), 0, st, p);
+  } else {
+    VG_REQUIRE(stats == nullptr, "thin_conv_fwd: statistics are only taken on the wide side");
+    p.wide = (const bf16_t*)x;
+    thin_tiles(p, p.TH_, p.TW_, 4, 32);
+    int rc = thin_lds_attr(thin_out_kernel<3, 1>, thin_out_lds<3>());
+    if (rc) return rc;
+    hipLaunchKernelGGL((thin_out_kernel<3, 1>), dim3(thin_out_blocks(p)), dim3(256), thin_out_lds<3>(), st, p);
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_thin_conv_dgrad(const vg_conv_desc* d, const void* dy, const float* w_oihw, void* dx, void* ws, void* stream) {
+  const int kind = vg_thin_conv_supported(d);
+  VG_REQUIRE(kind != 0, "thin_conv_dgrad: not a supported thin layer");
+  VG_REQUIRE(dy && w_oihw && dx && ws, "thin_conv_dgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  ThinParams p;
+  thin_fill(d, kind, p);
+  p.w = w_oihw; p.act = VG_ACT_NONE; p.out = (bf16_t*)dx; p.wpk = (const bf16_t*)ws;
+  p.wmode = kind == 2 ? 1 : (d->r == 3 ? 1 : 2);
+  hipLaunchKernelGGL(thin_pack_kernel, dim3(1), dim3(256), 0, st, p, (bf16_t*)ws, kind == 2 ? 1 : 0);
+  VG_LAUNCH_CHECK();
+  if (kind == 1) {          // dx thin <- dy wide
+    p.wide = (const bf16_t*)dy;
+    if (d->r == 3) {
+      p.wmode = 1; p.pad = d->r - 1 - d->pad;
+      thin_tiles(p, p.TH_, p.TW_, 4, 32);
+      int rc = thin_lds_attr(thin_out_kernel<3, 1>, thin_out_lds<3>());
+      if (rc) return rc;
+      hipLaunchKernelGGL((thin_out_kernel<3, 1>), dim3(thin_out_blocks(p)), dim3(256), thin_out_lds<3>(), st, p);
+    } else {
+      p.wmode = 2; p.pad = 1;
+      thin_tiles(p, p.WH, p.WW, 4, 32);          // tiles of the dy grid; each covers 8 x 64 pixels of dx
+      int rc = thin_lds_attr(thin_out_kernel<4, 2>, thin_out_lds<4>());
+      if (rc) return rc;
+      hipLaunchKernelGGL((thin_out_kernel<4, 2>), dim3(thin_out_blocks(p)), dim3(256), thin_out_lds<4>(), st, p);
+    }
+  } else {                  // dx wide <- dy thin
+    p.thin = (const bf16_t*)dy; p.wmode = 1; p.pad = d->r - 1 - d->pad;
+    thin_tiles(p, p.WH, p.WW, 8, 32);
+    hipLaunchKernelGGL((thin_in_kernel<3, 1>), dim3(p.ntiles), dim3(256), 0, st, p);
+  }
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+static int thin_wgrad_blocks(const ThinParams& p) { return p.ntiles < 512 ? p.ntiles : 512; }
+
+extern "C" size_t vg_thin_conv_wgrad_ws_bytes(const vg_conv_desc* d) {
+  const int kind = vg_thin_conv_supported(d);
+  if (!kind) return 0;
+  ThinParams p;
+  thin_fill(d, kind, p);
+  thin_tiles(p, p.WH, p.WW, 8, 32);
+  return (size_t)thin_wgrad_blocks(p) * 4096 * sizeof(float);
+}
+
+extern "C" int vg_thin_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws,
+                                  int accumulate, void* stream) {
+  const int kind = vg_thin_conv_supported(d);
+  VG_REQUIRE(kind != 0, "thin_conv_wgrad: not a supported thin layer");
+  VG_REQUIRE(x && dy && dw_oihw && ws, "thin_conv_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  ThinParams p;
+  thin_fill(d, kind, p);
+  p.part = (float*)ws;
+  if (kind == 1) { p.thin = (const bf16_t*)x; p.wide = (const bf16_t*)dy; p.wmode = 0; p.pad = d->pad; }
+  else { p.thin = (const bf16_t*)dy; p.wide = (const bf16_t*)x; p.wmode = 1; p.pad = d->r - 1 - d->pad; }
+  thin_tiles(p, p.WH, p.WW, 8, 32);
+  const int blocks = thin_wgrad_blocks(p);
+  if (d->r == 3) {
+    constexpr int lds = thin_wgrad_lds<3, 1>();
+    int rc = thin_lds_attr(thin_wgrad_kernel<3, 1>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((thin_wgrad_kernel<3, 1>), dim3(blocks), dim3(256), lds, st, p);
+  } else {
+    constexpr int lds = thin_wgrad_lds<4, 2>();
+    int rc = thin_lds_attr(thin_wgrad_kernel<4, 2>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((thin_wgrad_kernel<4, 2>), dim3(blocks), dim3(256), lds, st, p);
+  }
+  VG_LAUNCH_CHECK();
+  const int total = d->co * d->ci * d->r * d->r;
+  hipLaunchKernelGGL(thin_wgrad_finish_kernel, dim3((total + 63) / 64), dim3(64), 0, st, (const float*)ws, blocks, dw_oihw,
+                     d->co, d->ci, d->r, p.wmode, accumulate);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -66,6 +66,12 @@ SIGNATURES = {
     "vg_conv_fwd_bnstats": (_I, [_DP, _P, _P, _P, _I, C.POINTER(BnBwdStats), C.POINTER(C.c_int), _P]),
     "vg_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
     "vg_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
+    "vg_thin_conv_supported": (_I, [_DP]),
+    "vg_thin_conv_ws_bytes": (C.c_size_t, []),
+    "vg_thin_conv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "vg_thin_conv_dgrad": (_I, [_DP, _P, _P, _P, _P, _P]),
+    "vg_thin_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
+    "vg_thin_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
     "vg_channel_sum": (_I, [_P, _L, _I, _I, _I, _P, _P, _I, _P]),
     "vg_channel_sum_noalloc": (_I, [_P, _L, _I, _I, _I, _P, _I, _P]),
     "vg_nchw_to_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

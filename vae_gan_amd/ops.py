@@ -139,9 +139,23 @@ class ToNCHW(torch.autograd.Function):
         return _nchw_to_nhwc(g.contiguous().float(), ctx.cs, ctx.dt), None
 
 
+THIN_CS = 4     # channel stride of the 3-channel image-side tensors in bf16 mode (csrc/thin.hip): 8 bytes per pixel
+
+
+def _thin_enabled() -> bool:
+    return not _os.environ.get("VG_NO_THIN")
+
+
 def to_nhwc(x: torch.Tensor, dt: Optional[torch.dtype] = None) -> torch.Tensor:
     dt = dt or compute_dtype()
-    return ToNHWC.apply(x, L.pad_channels(x.shape[1], dt), dt)
+    c = x.shape[1]
+    cs = THIN_CS if (dt == torch.bfloat16 and c <= 3 and _thin_enabled()) else L.pad_channels(c, dt)
+    return ToNHWC.apply(x, cs, dt)
+
+
+def _relayout(t: torch.Tensor, c: int, cs: int) -> torch.Tensor:
+    """NHWC tensor with another channel stride (a thin tensor meeting a layer the thin kernels do not cover)."""
+    return _nchw_to_nhwc(_nhwc_to_nchw(t.contiguous(), c), cs, t.dtype)
 
 
 def to_nchw(x: torch.Tensor, c: int) -> torch.Tensor:
@@ -429,14 +443,37 @@ class Conv2dFn(torch.autograd.Function):
         co, ci, k, _ = weight.shape
         dt = x.dtype
         ycs = L.pad_channels(co, dt)
+        lib = L.load()
         d = _conv_desc(n, h, w, ci, co, k, stride, pad, xcs, ycs, dt)
-        wp = packs.get(weight, d, 0, dt)
+        # thin layers (3-channel side on a 4-channel NHWC tensor, csrc/thin.hip)
+        kind, ctx.thin_in_cs = 0, 0
+        if dt == torch.bfloat16:
+            if xcs == THIN_CS and ci <= 3:
+                kind = lib.vg_thin_conv_supported(C.byref(d))
+                if kind != 1:          # a geometry the thin kernels do not cover: back to the 32-padded layout
+                    kind, ctx.thin_in_cs = 0, xcs
+                    x = _relayout(x, ci, L.pad_channels(ci, dt))
+                    xcs = x.shape[-1]
+                    d = _conv_desc(n, h, w, ci, co, k, stride, pad, xcs, ycs, dt)
+            elif co <= 3 and _thin_enabled():
+                d4 = _conv_desc(n, h, w, ci, co, k, stride, pad, xcs, THIN_CS, dt)
+                if lib.vg_thin_conv_supported(C.byref(d4)) == 2:
+                    kind, d, ycs = 2, d4, THIN_CS
         y = torch.empty(n, d.oh, d.ow, ycs, dtype=dt, device=x.device)
         stats = _stats_buf(_npad(co), x.device) if want_stats else None
-        lib = L.load()
-        L.check(_timed(None, _conv_flops(d),
-                       lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(),
-                                               L.ptr(stats), act, 0, L.stream()), _shape_tag("fwd", d)), "conv_fwd")
+        if kind:
+            w32 = weight.detach().contiguous()
+            tws = torch.empty(lib.vg_thin_conv_ws_bytes(), dtype=torch.uint8, device=x.device)
+            L.check(_timed("thin_conv", _conv_flops(d),
+                           lambda: lib.vg_thin_conv_fwd(C.byref(d), x.data_ptr(), w32.data_ptr(), L.ptr(bias), y.data_ptr(),
+                                                        L.ptr(stats), act, tws.data_ptr(), L.stream()), _shape_tag("fwd", d)),
+                    "thin_conv_fwd")
+        else:
+            wp = packs.get(weight, d, 0, dt)
+            L.check(_timed(None, _conv_flops(d),
+                           lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(),
+                                                   L.ptr(stats), act, 0, L.stream()), _shape_tag("fwd", d)), "conv_fwd")
+        ctx.kind = kind
         ctx.d, ctx.act, ctx.packs, ctx.has_bias = d, act, packs, bias is not None
         ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x, weight, y if act != L.ACT_NONE else None)
@@ -455,6 +492,27 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.act != L.ACT_NONE:
             gy = _act_bwd(gy, y, ctx.act)
         dx = dw = db = None
+        if ctx.kind:            # thin layer: both gradients straight from the master weights
+            w32 = weight.detach().contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                tws = torch.empty(lib.vg_thin_conv_ws_bytes(), dtype=torch.uint8, device=x.device)
+                L.check(_timed("thin_conv", _conv_flops(d),
+                               lambda: lib.vg_thin_conv_dgrad(C.byref(d), gy.data_ptr(), w32.data_ptr(), dx.data_ptr(),
+                                                              tws.data_ptr(), L.stream()), _shape_tag("dgrad", d)), "thin_conv_dgrad")
+            if ctx.needs_input_grad[1]:
+                ws = torch.empty(lib.vg_thin_conv_wgrad_ws_bytes(C.byref(d)) // 4, dtype=torch.float32, device=x.device)
+                slot = _grad_slot(ctx.wparam)
+                dw = slot if slot is not None else torch.empty(weight.shape, dtype=torch.float32, device=x.device)
+                L.check(_timed("thin_conv", _conv_flops(d),
+                               lambda: lib.vg_thin_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                                              int(slot is not None), L.stream()), _shape_tag("wgrad", d)),
+                        "thin_conv_wgrad")
+                if slot is not None:
+                    dw = None
+            if ctx.has_bias and ctx.needs_input_grad[2] and not _bias_done(ctx.link):
+                db = _channel_sum(gy, d.co, ctx.bparam)
+            return dx, dw, db, None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             wpt = ctx.packs.get(weight, d, 1, x.dtype)
             parked = ctx.reslink.dres if ctx.reslink is not None else None
@@ -483,6 +541,8 @@ class Conv2dFn(torch.autograd.Function):
             dw = _wgrad(d, x, gy, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2] and not _bias_done(ctx.link):
             db = _channel_sum(gy, d.co, ctx.bparam)
+        if dx is not None and ctx.thin_in_cs:      # the input arrived in the thin layout: hand its gradient back the same way
+            dx = _relayout(dx, d.ci, ctx.thin_in_cs)
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
