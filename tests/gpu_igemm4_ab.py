@@ -1,0 +1,54 @@
+"""A/B of the weights-stationary kernel (igemm4) against the ping-pong kernel (igemm3) on the 64 -> 64 3x3 layer at the
+headline shape (B=64, 256x256): same inputs, same call, results compared bit for bit, times side by side."""
+import ctypes as C
+import sys
+import torch
+from vae_gan_amd import lib as L
+from gpu_ops_check import make_desc, pack
+
+
+def main(n=64, h=256, w=256, iters=10):
+    lib = L.load()
+    dt = torch.bfloat16
+    d = make_desc(n, h, w, 64, 64, 3, 1, 1, dt)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(n, h, w, d.xcs, device="cuda", generator=g).to(dt)
+    wt = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    gy = torch.randn(n, h, w, d.ycs, device="cuda", generator=g).to(dt)
+    bias = torch.linspace(-1, 1, 64, device="cuda")
+    wp, wpt = pack(lib, d, wt, 0, dt), pack(lib, d, wt, 1, dt)
+    res = {}
+    for mode, name in ((3 | 32, "igemm3"), (3, "igemm4")):
+        lib.vg_set_conv_kernel(mode)
+        y = torch.empty(n, h, w, d.ycs, dtype=dt, device="cuda")
+        dx = torch.empty(n, h, w, d.xcs, dtype=dt, device="cuda")
+        stats = torch.zeros(L.STATS_REPLICAS, 2, 64, dtype=torch.float64, device="cuda")
+        calls = (("fwd+bias+stats+lrelu", lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                                  stats.data_ptr(), 1, 0, L.stream())),
+                 ("dgrad", lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None, 0, 0, L.stream())))
+        line = []
+        for cname, fn in calls:
+            stats.zero_()
+            L.check(fn(), cname)
+            torch.cuda.synchronize()
+            kern = lib.vg_last_conv_kernel().decode()
+            keep = (y.clone(), dx.clone(), stats.sum(0).clone())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            line.append(f"{cname} {e0.elapsed_time(e1) / iters * 1e3:7.1f} us [{kern}]")
+            res[(name, cname)] = keep
+        print(f"{name}: " + " | ".join(line), flush=True)
+    lib.vg_set_conv_kernel(3)
+    a, b = res[("igemm3", "fwd+bias+stats+lrelu")], res[("igemm4", "fwd+bias+stats+lrelu")]
+    print("fwd equal bits:", torch.equal(a[0], b[0]), "max|d|", (a[0].float() - b[0].float()).abs().max().item(),
+          "stats rel", ((a[2] - b[2]).abs().max() / a[2].abs().max()).item())
+    a, b = res[("igemm3", "dgrad")], res[("igemm4", "dgrad")]
+    print("dgrad equal bits:", torch.equal(a[1], b[1]), "max|d|", (a[1].float() - b[1].float()).abs().max().item())
+
+
+if __name__ == "__main__":
+    main(*(int(v) for v in sys.argv[1:]))

@@ -118,6 +118,9 @@ CASES = [
     (1, 64, 64, 3, 64, 4, 2, 1),      # thin input (discriminator head): one 64-byte chunk per plane
     (1, 64, 128, 256, 512, 4, 2, 1),  # 256-channel config, 8 chunks per plane
     (1, 52, 60, 32, 64, 4, 2, 1),     # 64-channel config, 30-px rows
+    # weights-stationary persistent kernel (igemm4: 64 -> 64 3x3, whole 8 x 32 tiles)
+    (2, 32, 64, 64, 64, 3, 1, 1),     # fewer tiles than blocks
+    (6, 96, 128, 64, 64, 3, 1, 1),    # 288 tiles on 256 blocks: a second tile for some, XCD-ordered hand-out
 ]
 
 if __name__ == "__main__":

@@ -115,6 +115,9 @@ def test_dgrad_bnstats_matches_separate_reduce(gpu, case):
                                       C.byref(fused), L.stream()), "dgrad_bnstats")
     torch.cuda.synchronize()
     assert torch.equal(dx0, dx1)
+    if fused.value == 0:      # the weights-stationary kernel (64 -> 64, whole tiles, no accumulate) has no fused sums
+        assert lib.vg_last_conv_kernel().startswith(b"igemm4") and float(got.abs().max()) == 0.0, lib.vg_last_conv_kernel()
+        return
     assert fused.value == 1, lib.vg_last_conv_kernel()
     a = want.view(L.STATS_REPLICAS, 2, cpad).sum(0)
     b = got.view(L.STATS_REPLICAS, 2, cpad).sum(0)

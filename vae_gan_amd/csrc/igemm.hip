@@ -14,8 +14,10 @@
 
 #ifdef VG_ABLATE   // timing ablations only (results are wrong): see tests/gpu_conv_ablate.py
 #define VG_DBG(bit) (p.dbg & (bit))
+#define VG_ABLATE_LEVEL VG_ABLATE
 #else
 #define VG_DBG(bit) false
+#define VG_ABLATE_LEVEL 0
 #endif
 #define VG_MAX_PHASES 4
 #define VG_MAX_TAPS 16
@@ -1234,6 +1236,369 @@ template <typename T> static int dispatch_igemm3s2(const IgemmParams& p, hipStre
 }
 
 static int g_conv_kernel = 3;
+static bool g_conv_kernel_is_old() { return g_conv_kernel < 3; }
+
+// =============================================================================================
+// igemm4: weights-stationary persistent kernel for the 64 -> 64 channel 3x3 stride-1 gathers (the full-resolution
+// convolutions and their input gradients).  These layers hold the biggest tensors of the step and sit closest to the
+// HBM roofline, but in igemm3 every wave re-read its weight fragments from LDS on every K step (3 fragment reads per
+// 2 MFMAs: LDS-bound at ~2/3 of the MFMA rate), every block paid a prologue of one full memory latency, and the
+// epilogue of a block overlapped with nothing.
+// Here the WHOLE weight image (9 taps x 64 x 64 bf16 = 72 fragments = 288 registers) lives in the registers of every
+// wave, loaded once per block: a block is 4 waves (one per SIMD, so each may use the SIMD's 512 registers), it is
+// persistent and walks over 8 x 32 pixel tiles, a wave owning 2 pixel rows x 64 output channels (4 accumulators).
+// The halo image of tile i+1 arrives by LDS-DMA (out-of-image pieces from a block of zeros) while tile i is computed,
+// so the K loop has no weight traffic, no barriers and no waits: 2 LDS fragment reads per 4 MFMAs.  The output stores
+// of tile i drain under the MFMAs of tile i+1.  BatchNorm statistics stay in registers until the block ends.
+// Tiles are handed out so that the 32 blocks of an XCD work on 32 consecutive tiles (4 tile rows of a 256-wide image)
+// at a time: the halo rows two tiles share come out of that XCD's L2.
+// =============================================================================================
+// igemm4's timing switches perturb its schedule: only in a -DVG_ABLATE=2 build (=1: the cycle stamps alone)
+#define VG_DBG4(bit) (VG_ABLATE_LEVEL >= 2 && (p.dbg & (bit)))
+#ifndef VG_IGEMM4_PD
+#define VG_IGEMM4_PD 2
+#endif
+template <int R, int S, int CCH>
+struct Igemm4Cfg {
+  static constexpr int NT = 256, TW = 32, TH = 8, BM = TH * TW, BN = 64;
+  static constexpr int NTAPS = R * S, HS = 35, HSB = HS * 64, HH = TH + R - 1;
+  static constexpr int CHB = HH * HSB;                          // one channel chunk of a halo image
+  static constexpr int NPIECE = CCH * HH * HS * 4;              // 16-byte pieces per tile
+  static constexpr int HRN = (NPIECE + NT - 1) / NT;            // DMA rounds per tile
+  static constexpr int HBYTES = HRN * NT * 16;
+  static constexpr int WSTRIDE = BN + 8;                        // staging row: 64 channels + 16 B (bank spread)
+  static constexpr int WTILE = 2 * 32 * WSTRIDE * 2;            // per-wave output staging: 2 rows x 32 px x 64 ch bf16
+  static constexpr int OFF_STAGE = 2 * HBYTES;
+  static constexpr int OFF_TAB = OFF_STAGE + 4 * WTILE;         // [HRN][NT] halo piece table (offset, position)
+  static constexpr int LDS = OFF_TAB + HRN * NT * 8;
+  static constexpr bool FITS = LDS <= 160 * 1024 && NTAPS * CCH * 16 <= 320 && 4 * BN * 2 * 8 <= 4 * WTILE;
+};
+
+template <int R, int S, int CCH, bool LR, bool ST>
+__global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
+  typedef Igemm4Cfg<R, S, CCH> Cfg;
+  typedef bf16_t T;
+  constexpr int NT = Cfg::NT, TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, NTAPS = Cfg::NTAPS;
+  constexpr int HS = Cfg::HS, HSB = Cfg::HSB, HH = Cfg::HH, CHB = Cfg::CHB, HRN = Cfg::HRN, HBYTES = Cfg::HBYTES;
+  constexpr int PIECE = 8, WTILE = Cfg::WTILE, WSTRIDE = Cfg::WSTRIDE;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = pixel-row pair of the tile
+  const int h = lane >> 5, l32 = lane & 31;
+  const int phase = blockIdx.y;
+  const int py = phase / p.out_s, px = phase % p.out_s;
+  const int tpi = p.tilesX * p.tilesY;
+  const int dymin = p.dymin_i[phase], dxmin = p.dxmin_i[phase];
+  const bool flip = p.flip != 0;
+  const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
+  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
+  const unsigned smem0 = lds_addr_of(smem);
+
+  // ---- all weights: registers, once per block.  fb[tap][cc][kk][j]: k = cc*32 + kk*16 + 8h.., channel j*32 + l32
+  u32x4 fb[NTAPS][CCH][2][2];
+  {
+    const size_t ktot = (size_t)NTAPS * p.C;
+    const T* wg = (const T*)p.w + ((size_t)phase * p.Npad + l32) * ktot;
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap)
+#pragma unroll
+      for (int cc = 0; cc < CCH; ++cc)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            fb[tap][cc][kk][j] = *(const u32x4*)(wg + (size_t)j * 32 * ktot + (size_t)tap * p.C + cc * 32 + (2 * kk + h) * PIECE);
+  }
+  // ---- halo pieces of this thread (the same in every tile): piece q = rd*NT + tid of [CCH][HH*HS pixels][4 slots].
+  // The table lives in LDS: 2*HRN more live registers per lane would spill, and a spill reload is a vector memory
+  // load that queues behind the DMA it sits between.
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  i32x2* ptab = (i32x2*)(smem + Cfg::OFF_TAB) + tid;      // [rd * NT]: x = byte offset from the tile's origin pixel
+#pragma unroll                                           // (ty0 + dymin, tx0 + dxmin), chunk and slot included;
+  for (int rd = 0; rd < HRN; ++rd) {                      // y = (hy << 8) | hx, or -1: padding, never read
+    const int q = rd * NT + tid;
+    const int cc = q / (HH * HS * 4), rem = q - cc * (HH * HS * 4);
+    const int pix = rem >> 2, ps = rem & 3;
+    const int hy = pix / HS, hx = pix - hy * HS;
+    const bool ok = q < Cfg::NPIECE && hx < TW + S - 1;
+    ptab[rd * NT] = i32x2{((hy * p.W + hx) * p.Cs) * 2 + cc * 64 + (((ps ^ (hx >> 2)) & 3) << 4), ok ? ((hy << 8) | hx) : -1};
+  }
+  // tile k of this block: with the full grid of 256 blocks, the 32 blocks of an XCD (blockIdx % 8) take 32 consecutive tiles
+  const bool xcd_order = gridDim.x == 256;
+  auto tile_of = [&](int k) { return xcd_order ? ((k * 8 + (int)(blockIdx.x & 7)) * 32 + (int)(blockIdx.x >> 3)) : k * (int)gridDim.x + (int)blockIdx.x; };
+  auto tile_origin = [&](int tile, int& img, int& ty0, int& tx0) {
+    img = tile / tpi;
+    const int trem = tile - img * tpi;
+    const int ty = trem / p.tilesX;
+    ty0 = ty * TH; tx0 = (trem - ty * p.tilesX) * TW;
+  };
+  // A fragment addresses: column term per horizontal tap (slot of k half 0; ^32 is k half 1); rows are immediates
+  int ct[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int hx = l32 + (flip ? S - 1 - s : s);
+    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4) + 2 * wave * HSB;
+  }
+  float bv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    bv[j] = p.bias != nullptr ? p.bias[j * 32 + l32] : 0.f;
+  }
+  double st1[2] = {0.0, 0.0}, st2[2] = {0.0, 0.0};
+  T* __restrict__ yg = (T*)p.y;
+  T* wt = (T*)(smem + Cfg::OFF_STAGE + wave * WTILE);      // [2 rows][32 px][WSTRIDE]
+
+  // One halo round of tile `tile` into buffer `buf`: every lane issues (padding pieces fetch zeros into the buffer's
+  // padding), so a wave's DMA count per tile is always HRN.  `e` is this round's table entry, read a round ahead.
+  i32x2 e = ptab[0];
+  const unsigned char* hbase = nullptr;       // origin pixel of the tile being fetched
+  int hiy0 = 0, hix0 = 0;
+  auto halo_begin = [&](int tile) {
+    int img, ty0, tx0;
+    tile_origin(tile, img, ty0, tx0);
+    hiy0 = ty0 + dymin; hix0 = tx0 + dxmin;
+    hbase = xg + ((long)((long)img * p.H + hiy0) * p.W + hix0) * p.Cs * 2;
+  };
+  auto halo_round = [&](int rd, int buf) {
+    const int hy = e.y >> 8, hx = e.y & 255;
+    const bool in = e.y >= 0 && (unsigned)(hiy0 + hy) < (unsigned)p.H && (unsigned)(hix0 + hx) < (unsigned)p.W;
+    lds_dma16(in ? hbase + e.x : zsrc, smem0 + buf * HBYTES + (rd * NT + wave * 64) * 16);
+    e = ptab[(rd + 1 == HRN ? 0 : rd + 1) * NT];
+  };
+  // The output rows of a tile go to memory during the K loop of the NEXT tile, one 1 KB store every other step, and
+  // the halo of the next tile arrives the same way: a block that issued its loads and stores in bursts stalled at
+  // issue (the memory queues of a CU are short) with the matrix cores idle, and since every block runs the same
+  // schedule the whole chip alternated between an HBM-bound and an MFMA-bound phase.
+  auto stage_piece = [&](int sidx) {          // 16 bytes of this lane of deferred store sidx (row sidx / 4)
+    return *(const u32x4*)(wt + (sidx >> 2) * 32 * WSTRIDE + ((lane + 64 * (sidx & 3)) >> 3) * WSTRIDE + (lane & 7) * PIECE);
+  };
+  T* pdst = nullptr;                          // previous tile: first output row of this wave, this lane's piece
+  auto store_piece = [&](int sidx, u32x4 v) {
+    if (!VG_DBG4(32)) *(u32x4*)(pdst + (size_t)(sidx >> 2) * p.OW * BN + (sidx & 3) * 512) = v;
+  };
+
+#ifdef VG_ABLATE   // s_memtime ticks per stage, summed over the block's tiles (wave 0): tests/gpu_igemm4_stamps.py
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long tstart = tlast;
+#define VG_T(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define VG_T(i) do {} while (0)
+#endif
+  int tile = tile_of(0);
+  if (tile < p.mtiles) {
+    halo_begin(tile);
+#pragma unroll
+    for (int rd = 0; rd < HRN; ++rd) halo_round(rd, 0);
+  }
+  wait_vmcnt<0>();
+  bool has_prev = false;
+  int buf = 0;
+  for (int k = 0; tile < p.mtiles; ++k, buf ^= 1) {
+    const int next = tile_of(k + 1);
+    const bool has_next = next < p.mtiles && !VG_DBG4(1);
+    int img, ty0, tx0;
+    tile_origin(tile, img, ty0, tx0);
+    if (has_next) halo_begin(next);
+    __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
+    VG_T(0);
+    f32x16 acc[2][2];                  // written by the MFMAs of the first K step (C = 0)
+    const unsigned char* hb = smem + buf * HBYTES;
+    // K loop, 36 steps of 4 MFMAs, fully unrolled; the two A fragments of step t+PD are requested before the MFMAs of
+    // step t (one wave per SIMD: nobody else hides the LDS latency)
+    constexpr int KSTEPS = CCH * NTAPS * 2;
+    static_assert(2 * HRN <= KSTEPS - 8, "halo rounds on the even steps, done well before the loop ends");
+    auto a_addr = [&](int t) {
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
+      const int r = tap / S, s = tap % S;
+      const int va0 = ct[s] + cc * CHB + (flip ? R - 1 - r : r) * HSB;
+      return kk ? va0 ^ 32 : va0;
+    };
+    constexpr int PD = VG_IGEMM4_PD;      // prefetch distance in K steps
+    constexpr int AFRAGS = 64;
+    u32x4 fa[PD + 1][2];
+    u32x4 sreg = u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < PD; ++t) {
+      const int va = a_addr(t);
+      fa[t][0] = *(const u32x4*)(hb + va); fa[t][1] = *(const u32x4*)(hb + va + HSB);
+    }
+#pragma unroll
+    for (int t = 0; t < KSTEPS; ++t) {
+      if (t + PD < KSTEPS) {
+        const int va = a_addr(t + PD);
+        fa[(t + PD) % (PD + 1)][0] = *(const u32x4*)(hb + va); fa[(t + PD) % (PD + 1)][1] = *(const u32x4*)(hb + va + HSB);
+      }
+      if (t % 2 == 0 && t / 2 < HRN) { if (has_next) halo_round(t / 2, buf ^ 1); }
+      if (t % 2 == 0 && t / 2 < 8) { if (has_prev) sreg = stage_piece(t / 2); }
+      if (t % 2 == 1 && t / 2 < 8) { if (has_prev) store_piece(t / 2, sreg); }
+      __builtin_amdgcn_sched_barrier(0);
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
+      if (VG_DBG4(16) && t >= 2) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // the first AFRAGS weight fragments live in accumulation registers, the rest (and the accumulators) in
+        // ordinary ones: 288 + 64 registers do not fit either file alone.  With the builtin the compiler kept the
+        // weights in accumulation registers but copied every fragment into the same four ordinary ones in front of its
+        // MFMAs (it never names an accumulation register as a multiplicand), and those copies had to wait for the
+        // previous MFMA to read them: 62 % of the MFMA rate.
+        const bool in_a = ((tap * CCH + cc) * 2 + kk) * 2 + j < AFRAGS;
+        if (t == 0) {
+          static_assert(AFRAGS >= 2, "the first step's fragments are in accumulation registers");
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[0][j]) : "v"(fa[0][0]), "a"(fb[tap][cc][kk][j]));
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[1][j]) : "v"(fa[0][1]), "a"(fb[tap][cc][kk][j]));
+        } else if (in_a) {
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][j]) : "v"(fa[t % (PD + 1)][0]), "a"(fb[tap][cc][kk][j]));
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][j]) : "v"(fa[t % (PD + 1)][1]), "a"(fb[tap][cc][kk][j]));
+        } else {
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][j]) : "v"(fa[t % (PD + 1)][0]), "v"(fb[tap][cc][kk][j]));
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][j]) : "v"(fa[t % (PD + 1)][1]), "v"(fb[tap][cc][kk][j]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+    VG_T(1);
+    // ---- epilogue (every tile is whole, all 64 channels are real: the launcher's conditions): BatchNorm statistics of
+    // the bf16-rounded pre-activation, activation; both pixel rows into the wave's staging tile (stored next tile)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (VG_DBG4(64)) continue;
+      T* wl = wt + i * 32 * WSTRIDE + 4 * h * WSTRIDE + l32;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x2 a1 = f32x2{0.f, 0.f}, a2 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int r2 = 0; r2 < 8; ++r2) {
+          const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2);
+          f32x2 v = f32x2{acc[i][j][r], acc[i][j][r + 1]} + bv[j];
+          bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+          if (ST || LR) v = __builtin_convertvector(q, f32x2);
+          if (ST) { a1 += v; a2 += v * v; }
+          if (LR) {
+            const f32x2 w = v * VG_LRELU_SLOPE;
+            f32x2 m;
+            asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
+            q = __builtin_convertvector(m, bf16x2_t);
+          }
+          wl[row * WSTRIDE + j * 32] = q[0];
+          wl[(row + 1) * WSTRIDE + j * 32] = q[1];
+        }
+        if (ST) { st1[j] += (double)(a1[0] + a1[1]); st2[j] += (double)(a2[0] + a2[1]); }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    pdst = yg + ((((size_t)img * p.OH + ty0 + 2 * wave) * p.OW + tx0) * BN + lane * PIECE);
+    has_prev = !VG_DBG4(64);
+    // halo rounds and stores were issued in the first 2/3 of the K loop: (nearly) free by now, and it makes the barrier
+    // at the top of the next iteration mean "the next halo is in LDS"
+    VG_T(2);
+    wait_vmcnt<0>();
+    VG_T(3);
+    tile = next;
+  }
+#ifdef VG_ABLATE
+  if (VG_DBG(8) && p.splitws && tid == 0) {
+    unsigned long long* stamps = (unsigned long long*)p.splitws + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 4; ++i) stamps[i] = tacc[i];
+    stamps[4] = __builtin_amdgcn_s_memtime() - tstart;
+    stamps[5] = tstart;
+  }
+#endif
+#undef VG_T
+  if (has_prev) {
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) store_piece(sidx, stage_piece(sidx));
+  }
+  if (ST) {
+    __syncthreads();
+    double* red = (double*)(smem + Cfg::OFF_STAGE);      // [4 waves][BN][2]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const double s1 = st1[j] + __shfl_xor(st1[j], 32, 64), s2 = st2[j] + __shfl_xor(st2[j], 32, 64);
+      if (h == 0) { red[(wave * BN + j * 32 + l32) * 2 + 0] = s1; red[(wave * BN + j * 32 + l32) * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    if (tid < BN && tid < p.Nout) {
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+      const int rep = (blockIdx.x + phase) % VG_STATS_REPLICAS;
+      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.Npad + tid], t1);
+      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + tid], t2);
+    }
+  }
+}
+
+static bool g_igemm4 = true;
+template <int R, int S, int CCH, bool LR, bool ST>
+static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
+  typedef Igemm4Cfg<R, S, CCH> Cfg;
+  static_assert(Cfg::FITS, "igemm4 configuration does not fit");
+  *handled = false;
+  IgemmParams p = p0;
+  int flip = -1;       // the tap grid must be R x S, row-major, offsets all ascending or all descending (as for igemm3)
+  {
+    int ymin = 127, xmin = 127;
+    for (int t = 0; t < p.ntaps; ++t) {
+      ymin = p.dy[0][t] < ymin ? p.dy[0][t] : ymin;
+      xmin = p.dx[0][t] < xmin ? p.dx[0][t] : xmin;
+    }
+    p.dymin[0] = (signed char)ymin; p.dxmin[0] = (signed char)xmin;
+    bool asc = true, desc = true;
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int yo = p.dy[0][t] - ymin, xo = p.dx[0][t] - xmin;
+      asc = asc && yo == t / S && xo == t % S;
+      desc = desc && yo == R - 1 - t / S && xo == S - 1 - t % S;
+    }
+    flip = asc ? 0 : (desc ? 1 : -1);
+    if (flip < 0) return VG_OK;
+  }
+  p.flip = flip;
+  if ((size_t)p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31)) return VG_OK;        // piece offsets inside one image are 32-bit
+  p.tilesX = p.OWl / Cfg::TW;
+  p.tilesY = p.OHl / Cfg::TH;
+  p.mtiles = p.N * p.tilesX * p.tilesY;
+  p.ntiles = 1;
+  p.dbg = g_dbg;
+#ifdef VG_ABLATE
+  p.splitws = (float*)g_stamp_buf;
+#endif
+  auto kern = igemm4_kernel<R, S, CCH, LR, ST>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+    attr_set = true;
+  }
+  pack_taps(p);
+  const int blocks = p.mtiles < 256 ? p.mtiles : 256;    // one persistent block per CU
+  snprintf(g_last_kernel, sizeof g_last_kernel, "igemm4<bf16,%dx%d,%d>", R, S, CCH);
+  hipLaunchKernelGGL(kern, dim3(blocks, 1), dim3(Cfg::NT), Cfg::LDS, st, p);
+  VG_LAUNCH_CHECK();
+  *handled = true;
+  return VG_OK;
+}
+template <typename T> static int dispatch_igemm4(const IgemmParams& p, hipStream_t st, bool* handled) {
+  *handled = false;
+  if constexpr (sizeof(T) == 2) {
+    // whole 8 x 32 tiles, 64 real output channels at stride 64, no read-modify-write: everything else stays on igemm3
+    if (!g_igemm4 || g_conv_kernel_is_old() || p.ksplit > 1 || p.in_s != 1 || p.nphases != 1 || p.Npad != 64 || p.Nout != 64 ||
+        p.Ks != 64 || p.out_s != 1 || p.accumulate || p.OWl % 32 != 0 || p.OHl % 8 != 0 || (p.act != VG_ACT_NONE && p.act != VG_ACT_LRELU))
+      return VG_OK;
+    if (p.ntaps == 9 && p.C == 64) {
+      const bool lr = p.act == VG_ACT_LRELU, st_ = p.stats != nullptr;
+      if (lr) return st_ ? launch_igemm4<3, 3, 2, true, true>(p, st, handled) : launch_igemm4<3, 3, 2, true, false>(p, st, handled);
+      return st_ ? launch_igemm4<3, 3, 2, false, true>(p, st, handled) : launch_igemm4<3, 3, 2, false, false>(p, st, handled);
+    }
+  }
+  return VG_OK;
+}
+
 template <typename T, int R, int S> static int dispatch_igemm3_rs(const IgemmParams& p, hipStream_t st, bool* handled) {
   if (p.Npad % 256 == 0) return launch_igemm3<T, 4, 2, 2, 4, R, S>(p, st, handled);   // 8x32 px x 256 ch
   if (p.Npad == 128) {
@@ -1267,6 +1632,7 @@ static bool g_use_igemm2 = true;
 extern "C" void vg_set_conv_kernel(int version) {
   g_conv_kernel = version & 0x0f;                 // bit 4 (16): stride-2 forward stays on the im2col-row kernel
   g_igemm3_s2 = !(version & 0x10);
+  g_igemm4 = !(version & 0x20);                   // bit 5 (32): no weights-stationary kernel (the 64-channel layers stay on igemm3)
   g_use_igemm2 = g_conv_kernel != 1;
   g_dbg = version >> 8;
 }
@@ -1289,6 +1655,8 @@ template <typename T> static int dispatch_igemm2(const IgemmParams& p, hipStream
 
 template <typename T> static int dispatch_igemm(const IgemmParams& p, hipStream_t st) {
   bool handled = false;
+  int rc4 = dispatch_igemm4<T>(p, st, &handled);
+  if (rc4 != VG_OK || handled) return rc4;
   int rc3 = dispatch_igemm3<T>(p, st, &handled);
   if (rc3 != VG_OK || handled) return rc3;
   int rc2 = dispatch_igemm2<T>(p, st, &handled);
