@@ -22,17 +22,20 @@ def main(n=64, h=256, w=256, iters=10):
         lib.vg_set_conv_kernel(mode)
         y = torch.empty(n, h, w, d.ycs, dtype=dt, device="cuda")
         dx = torch.empty(n, h, w, d.xcs, dtype=dt, device="cuda")
+        dxa = torch.empty(n, h, w, d.xcs, dtype=dt, device="cuda")
         stats = torch.zeros(L.STATS_REPLICAS, 2, 64, dtype=torch.float64, device="cuda")
         calls = (("fwd+bias+stats+lrelu", lambda: lib.vg_conv_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                                                   stats.data_ptr(), 1, 0, L.stream())),
-                 ("dgrad", lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None, 0, 0, L.stream())))
+                 ("dgrad", lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None, 0, 0, L.stream())),
+                 ("dgrad+acc", lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dxa.data_ptr(), None, 0, 1, L.stream())))
         line = []
         for cname, fn in calls:
             stats.zero_()
+            dxa.copy_(x)
             L.check(fn(), cname)
             torch.cuda.synchronize()
             kern = lib.vg_last_conv_kernel().decode()
-            keep = (y.clone(), dx.clone(), stats.sum(0).clone())
+            keep = (y.clone(), dx.clone(), stats.sum(0).clone(), dxa.clone())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
@@ -48,6 +51,8 @@ def main(n=64, h=256, w=256, iters=10):
           "stats rel", ((a[2] - b[2]).abs().max() / a[2].abs().max()).item())
     a, b = res[("igemm3", "dgrad")], res[("igemm4", "dgrad")]
     print("dgrad equal bits:", torch.equal(a[1], b[1]), "max|d|", (a[1].float() - b[1].float()).abs().max().item())
+    a, b = res[("igemm3", "dgrad+acc")], res[("igemm4", "dgrad+acc")]
+    print("dgrad+acc equal bits:", torch.equal(a[3], b[3]), "max|d|", (a[3].float() - b[3].float()).abs().max().item())
 
 
 if __name__ == "__main__":

@@ -1274,7 +1274,7 @@ struct Igemm4Cfg {
   static constexpr bool FITS = LDS <= 160 * 1024 && NTAPS * CCH * 16 <= 320 && 4 * BN * 2 * 8 <= 4 * WTILE;
 };
 
-template <int R, int S, int CCH, bool LR, bool ST>
+template <int R, int S, int CCH, bool LR, bool ST, bool ACC>
 __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   typedef Igemm4Cfg<R, S, CCH> Cfg;
   typedef bf16_t T;
@@ -1376,9 +1376,20 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     return *(const u32x4*)(wt + (sidx >> 2) * 32 * WSTRIDE + ((lane + 64 * (sidx & 3)) >> 3) * WSTRIDE + (lane & 7) * PIECE);
   };
   T* pdst = nullptr;                          // previous tile: first output row of this wave, this lane's piece
-  auto store_piece = [&](int sidx, u32x4 v) {
-    if (!VG_DBG4(32)) *(u32x4*)(pdst + (size_t)(sidx >> 2) * p.OW * BN + (sidx & 3) * 512) = v;
+  auto store_ptr = [&](int sidx) { return pdst + (size_t)(sidx >> 2) * p.OW * BN + (sidx & 3) * 512; };
+  auto store_piece = [&](int sidx, u32x4 v, u32x4 old) {
+    if (ACC) {               // y += conv: bf16(bf16(conv) + y), the rounding order of the other kernels' read-modify-write
+      Piece<T> o, q;
+      o.v = __builtin_bit_cast(bf16x8, v); q.v = __builtin_bit_cast(bf16x8, old);
+#pragma unroll
+      for (int e_ = 0; e_ < PIECE; ++e_) o.set(e_, o.get(e_) + q.get(e_));
+      v = __builtin_bit_cast(u32x4, o.v);
+    }
+    if (!VG_DBG4(32)) *(u32x4*)store_ptr(sidx) = v;
   };
+  // ACC: the old values of the previous tile's rows are requested in one burst when the K loop starts and the stores
+  // sit in its second half; the end-of-tile wait then lets the stores issued after the last halo round stay in flight
+  constexpr int ST0 = ACC ? 18 : 0;
 
 #ifdef VG_ABLATE   // s_memtime ticks per stage, summed over the block's tiles (wave 0): tests/gpu_igemm4_stamps.py
   unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -1420,6 +1431,9 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     constexpr int AFRAGS = 64;
     u32x4 fa[PD + 1][2];
     u32x4 sreg = u32x4{0, 0, 0, 0};
+    u32x4 oreg[8];
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) oreg[sidx] = u32x4{0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < PD; ++t) {
       const int va = a_addr(t);
@@ -1432,8 +1446,14 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
         fa[(t + PD) % (PD + 1)][0] = *(const u32x4*)(hb + va); fa[(t + PD) % (PD + 1)][1] = *(const u32x4*)(hb + va + HSB);
       }
       if (t % 2 == 0 && t / 2 < HRN) { if (has_next) halo_round(t / 2, buf ^ 1); }
-      if (t % 2 == 0 && t / 2 < 8) { if (has_prev) sreg = stage_piece(t / 2); }
-      if (t % 2 == 1 && t / 2 < 8) { if (has_prev) store_piece(t / 2, sreg); }
+      if (ACC && t == 0) {
+        if (has_prev) {
+#pragma unroll
+          for (int sidx = 0; sidx < 8; ++sidx) oreg[sidx] = *(const u32x4*)store_ptr(sidx);
+        }
+      }
+      if (t >= ST0 && (t - ST0) % 2 == 0 && (t - ST0) / 2 < 8) { if (has_prev) sreg = stage_piece((t - ST0) / 2); }
+      if (t >= ST0 && (t - ST0) % 2 == 1 && (t - ST0) / 2 < 8) { if (has_prev) store_piece((t - ST0) / 2, sreg, oreg[(t - ST0) / 2]); }
       __builtin_amdgcn_sched_barrier(0);
       const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
       if (VG_DBG4(16) && t >= 2) continue;
@@ -1498,7 +1518,11 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     // halo rounds and stores were issued in the first 2/3 of the K loop: (nearly) free by now, and it makes the barrier
     // at the top of the next iteration mean "the next halo is in LDS"
     VG_T(2);
-    wait_vmcnt<0>();
+    {
+      // stores issued after the last halo round (K step 2*HRN-2): they may stay in flight
+      constexpr int LATE = [] { int n = 0; for (int s_ = 0; s_ < 8; ++s_) n += ST0 + 1 + 2 * s_ > 2 * HRN - 2; return n; }();
+      if (ACC && has_prev && VG_ABLATE_LEVEL < 2) wait_vmcnt<LATE>(); else wait_vmcnt<0>();
+    }
     VG_T(3);
     tile = next;
   }
@@ -1513,7 +1537,11 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
 #undef VG_T
   if (has_prev) {
 #pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) store_piece(sidx, stage_piece(sidx));
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      u32x4 old = u32x4{0, 0, 0, 0};
+      if (ACC) old = *(const u32x4*)store_ptr(sidx);
+      store_piece(sidx, stage_piece(sidx), old);
+    }
   }
   if (ST) {
     __syncthreads();
@@ -1536,7 +1564,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
 }
 
 static bool g_igemm4 = true;
-template <int R, int S, int CCH, bool LR, bool ST>
+template <int R, int S, int CCH, bool LR, bool ST, bool ACC>
 static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
   typedef Igemm4Cfg<R, S, CCH> Cfg;
   static_assert(Cfg::FITS, "igemm4 configuration does not fit");
@@ -1569,7 +1597,7 @@ static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
 #ifdef VG_ABLATE
   p.splitws = (float*)g_stamp_buf;
 #endif
-  auto kern = igemm4_kernel<R, S, CCH, LR, ST>;
+  auto kern = igemm4_kernel<R, S, CCH, LR, ST, ACC>;
   static bool attr_set = false;
   if (!attr_set) {
     VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
@@ -1586,14 +1614,18 @@ static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
 template <typename T> static int dispatch_igemm4(const IgemmParams& p, hipStream_t st, bool* handled) {
   *handled = false;
   if constexpr (sizeof(T) == 2) {
-    // whole 8 x 32 tiles, 64 real output channels at stride 64, no read-modify-write: everything else stays on igemm3
+    // whole 8 x 32 tiles, 64 real output channels at stride 64: everything else stays on igemm3
     if (!g_igemm4 || g_conv_kernel_is_old() || p.ksplit > 1 || p.in_s != 1 || p.nphases != 1 || p.Npad != 64 || p.Nout != 64 ||
-        p.Ks != 64 || p.out_s != 1 || p.accumulate || p.OWl % 32 != 0 || p.OHl % 8 != 0 || (p.act != VG_ACT_NONE && p.act != VG_ACT_LRELU))
+        p.Ks != 64 || p.out_s != 1 || p.OWl % 32 != 0 || p.OHl % 8 != 0 || (p.act != VG_ACT_NONE && p.act != VG_ACT_LRELU))
       return VG_OK;
     if (p.ntaps == 9 && p.C == 64) {
       const bool lr = p.act == VG_ACT_LRELU, st_ = p.stats != nullptr;
-      if (lr) return st_ ? launch_igemm4<3, 3, 2, true, true>(p, st, handled) : launch_igemm4<3, 3, 2, true, false>(p, st, handled);
-      return st_ ? launch_igemm4<3, 3, 2, false, true>(p, st, handled) : launch_igemm4<3, 3, 2, false, false>(p, st, handled);
+      if (p.accumulate) {      // input gradients onto a parked skip gradient: no activation, no statistics
+        if (lr || st_) return VG_OK;
+        return launch_igemm4<3, 3, 2, false, false, true>(p, st, handled);
+      }
+      if (lr) return st_ ? launch_igemm4<3, 3, 2, true, true, false>(p, st, handled) : launch_igemm4<3, 3, 2, true, false, false>(p, st, handled);
+      return st_ ? launch_igemm4<3, 3, 2, false, true, false>(p, st, handled) : launch_igemm4<3, 3, 2, false, false, false>(p, st, handled);
     }
   }
   return VG_OK;
