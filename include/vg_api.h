@@ -27,6 +27,16 @@ enum { VG_ACT_NONE = 0, VG_ACT_LRELU = 1, VG_ACT_SIGMOID = 2 };
 
 #define VG_STATS_REPLICAS 32 /* per-channel f64 accumulators are spread over this many copies */
 
+/* Reproducible runs (no counterpart in the reference, whose CUDA kernels are not reproducible either).
+ * on != 0: every per-channel statistics buffer ([VG_STATS_REPLICAS][...] f64 slots in the entry points below) is
+ * accumulated as 64-bit fixed-point bins instead of doubles (integer adds: any order gives the same bits; the caller
+ * still only zeroes the buffer and hands it back to the consuming entry point; across ranks it must be summed as
+ * int64), the kernels that split a reduction over blocks through f32 atomics (im2col-row weight gradient, split-K
+ * forward) run unsplit, and the VQ EMA sums are taken in row order.  Two runs of the same step then give the same
+ * bits.  Process-wide; set it before the buffers of a step are filled, not between a producer and its consumer. */
+void vg_set_deterministic(int on);
+int vg_get_deterministic(void);
+
 const char* vg_last_error(void);
 int vg_version(void);
 

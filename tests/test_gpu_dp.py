@@ -235,7 +235,8 @@ def test_rccl_stream_path_one_rank():
     out = mp.Manager().dict()
     mp.spawn(_worker_rccl, args=(1, _free_port(), out), nprocs=1, join=True)
     c = out.get(0)
-    assert c and c["d_loss"] and c["g_loss"] and c["idx"] and c["grads"] < 3e-2 and c["n_async"] == 1 and c["exact_identity"], c
-    # (two runs of the same step differ by 1e-4..3e-3 in the flat gradient: atomics order -> LeakyReLU sign flips, the
-    #  module-level noise floor of DESIGN.md §2; a broken exchange would be O(1) off, and the synthetic buffer above
-    #  pins the exchange exactly)
+    # The f32 mode is reproducible (vg_set_deterministic; tests/test_gpu_determinism.py) and a sum over one rank is an
+    # identity, so what is left between the two runs is the different association of the gradient accumulation that the
+    # bucket boundaries bring (measured 4e-6 rel-L2 on the whole flat gradient); the synthetic buffer pins the exchange
+    # itself exactly.
+    assert c and c["d_loss"] and c["g_loss"] and c["idx"] and c["grads"] < 1e-5 and c["n_async"] == 1 and c["exact_identity"], c

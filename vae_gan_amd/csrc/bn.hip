@@ -7,15 +7,11 @@
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int c, int cpad, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, int64_t* num_batches,
-                                   int updates, float* mean, float* invstd, float* scale, float* shift) {
+                                   int updates, float* mean, float* invstd, float* scale, float* shift, int det) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch == 0 && num_batches != nullptr) *num_batches += updates;
   if (ch >= c) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < VG_STATS_REPLICAS; ++r) {
-    s1 += stats[((size_t)r * 2 + 0) * cpad + ch];
-    s2 += stats[((size_t)r * 2 + 1) * cpad + ch];
-  }
+  const double s1 = vg_stats_read(stats, cpad, 0, ch, det), s2 = vg_stats_read(stats, cpad, 1, ch, det);
   double m = s1 / count;
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -45,7 +41,7 @@ extern "C" int vg_bn_finalize(const double* stats, int c, int cpad, int64_t coun
              "bn_finalize: bad arguments");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, c, cpad,
                      (double)count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, updates, mean,
-                     invstd, scale, shift);
+                     invstd, scale, shift, vg_det_mode());
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -169,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, double* __restrict__ sums,
-                                                            int64_t rows, int cs, int c, int cpad, int act) {
+                                                            int64_t rows, int cs, int c, int cpad, int act, int det) {
   constexpr int PIECE = Elt<T>::PIECE;
   __shared__ float red[256 * PIECE * 2];
   const int ppr = cs / PIECE;                        // pieces per row (<= 256 guaranteed by launcher)
@@ -241,12 +237,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
   }
   __syncthreads();
-  const int rep = blockIdx.x % VG_STATS_REPLICAS;
   for (int ch = threadIdx.x; ch < c; ch += 256) {
     double t1 = 0.0, t2 = 0.0;
     for (int r = 0; r < rpb; ++r) { t1 += red[(r * width + ch) * 2]; t2 += red[(r * width + ch) * 2 + 1]; }
-    unsafeAtomicAdd(&sums[((size_t)rep * 2 + 0) * cpad + ch], t1);
-    unsafeAtomicAdd(&sums[((size_t)rep * 2 + 1) * cpad + ch], t2);
+    vg_stats_add(sums, cpad, 0, ch, blockIdx.x, t1, det);
+    vg_stats_add(sums, cpad, 1, ch, blockIdx.x, t2, det);
   }
 }
 
@@ -264,13 +259,14 @@ extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, 
   if (blocks > 2048) blocks = 2048;
   hipStream_t st = (hipStream_t)stream;
   if (y == nullptr && !xmask) y = x;    // no activation: the value is never looked at
+  const int det = vg_det_mode();
   dim3 g((unsigned)blocks), b(256);
   if (dtype == VG_BF16) {
-    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
+    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
   } else {
-    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act);
+    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
   }
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -283,14 +279,10 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
                                    const float* __restrict__ mean,
                                    float* __restrict__ coef /* [3][cpad]: dx = ca*dz - cb - cx*x */,
-                                   float* dgamma, float* dbeta, int accumulate, float dgb_scale, float* dxsum) {
+                                   float* dgamma, float* dbeta, int accumulate, float dgb_scale, float* dxsum, int det) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < VG_STATS_REPLICAS; ++r) {
-    s1 += sums[((size_t)r * 2 + 0) * cpad + ch];
-    s2 += sums[((size_t)r * 2 + 1) * cpad + ch];
-  }
+  const double s1 = vg_stats_read(sums, cpad, 0, ch, det), s2 = vg_stats_read(sums, cpad, 1, ch, det);
   // d = a*(dz - m1 - xh*m2), xh = (x-mu)*is  ==  a*dz - (a*m1 - a*m2*is*mu) - (a*m2*is)*x
   const float a = (gamma ? gamma[ch] : 1.f) * invstd[ch], m1 = (float)(s1 / count), m2 = (float)(s2 / count);
   const float cx = a * m2 * invstd[ch];
@@ -408,7 +400,7 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   // local statistics (count = rows): the bias gradient comes out of the coefficient kernel in closed form; with
   // global-batch statistics (count > rows) the rank's own sum of dx is not zero and the apply kernel adds it up.
   const bool closed = dxsum != nullptr && (count <= 0 || count == rows);
-  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)(count > 0 ? count : rows), gamma, invstd, mean, coef, dgamma, dbeta, accumulate, dgb_scale, closed ? dxsum : (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 127) / 128), dim3(128), 0, st, sums, c, cpad, (double)(count > 0 ? count : rows), gamma, invstd, mean, coef, dgamma, dbeta, accumulate, dgb_scale, closed ? dxsum : (float*)nullptr, vg_det_mode());
   VG_LAUNCH_CHECK();
   if (closed) dxsum = nullptr;
   const int ppr = cs / piece;
@@ -496,7 +488,7 @@ extern "C" int vg_add_inplace(void* a, const void* b, int64_t n, int dtype, void
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int64_t rows,
-                                                            int cs, int c, int cpad) {
+                                                            int cs, int c, int cpad, int det) {
   constexpr int PIECE = Elt<T>::PIECE;
   __shared__ float red[256 * PIECE * 2];
   const int ppr = cs / PIECE, rpb = 256 / ppr;
@@ -528,12 +520,11 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict_
     }
   }
   __syncthreads();
-  const int rep = blockIdx.x % VG_STATS_REPLICAS;
   for (int ch = threadIdx.x; ch < c; ch += 256) {
     double t1 = 0.0, t2 = 0.0;
     for (int r = 0; r < rpb; ++r) { t1 += red[(r * width + ch) * 2]; t2 += red[(r * width + ch) * 2 + 1]; }
-    unsafeAtomicAdd(&stats[((size_t)rep * 2 + 0) * cpad + ch], t1);
-    unsafeAtomicAdd(&stats[((size_t)rep * 2 + 1) * cpad + ch], t2);
+    vg_stats_add(stats, cpad, 0, ch, blockIdx.x, t1, det);
+    vg_stats_add(stats, cpad, 1, ch, blockIdx.x, t2, det);
   }
 }
 
@@ -544,8 +535,8 @@ extern "C" int vg_channel_stats(const void* x, double* stats, int64_t rows, int 
   const int rpb = 256 / (cs / piece);
   int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 16);
   if (blocks > 2048) blocks = 2048;
-  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats, rows, cs, c, cpad);
-  else hipLaunchKernelGGL(channel_stats_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, stats, rows, cs, c, cpad);
+  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats, rows, cs, c, cpad, vg_det_mode());
+  else hipLaunchKernelGGL(channel_stats_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, stats, rows, cs, c, cpad, vg_det_mode());
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

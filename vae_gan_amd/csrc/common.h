@@ -82,6 +82,60 @@ template <> struct Piece<bf16_t> {
   __device__ inline void set(int i, float f) { v[i] = (bf16_t)f; }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Per-channel statistics accumulators: stats[VG_STATS_REPLICAS][2][cpad], 8 bytes per slot, zeroed by the caller.
+//   det == 0: the slots are doubles; a block adds its partial sum to replica (hint % VG_STATS_REPLICAS) with an f64
+//             atomic.  The order of the adds, hence the last bits of the sum, changes from run to run.
+//   det != 0: the slots are 64-bit integers, a fixed-point superaccumulator: a partial sum is cut into f32 pieces
+//             (exactly), a piece M * 2^(E-150) (24-bit mantissa M) is added as the integer M << (E % 24) to bin E / 24
+//             (VG_DET_BINS bins x 2 sub-replicas fill 22 of the 32 replica slots).  Integer addition is associative, so
+//             the slots, and everything computed from them, are the same bits on every run.  47-bit addends leave room
+//             for 2^16 adds per slot.  Pieces below 2^-126 are dropped.
+// vg_stats_read sums the slots in a fixed order either way.  (vg_api.h: vg_set_deterministic.)
+// ---------------------------------------------------------------------------------------------
+#define VG_DET_BINS 11
+int vg_det_mode(void);      // host: the library-wide switch (pack.hip)
+// slot0 = replica 0 of the accumulator, rep_stride = distance (in slots) between replicas
+__device__ inline void vg_acc_add(double* slot0, size_t rep_stride, unsigned hint, double v, int det) {
+  if (!det) {
+    unsafeAtomicAdd(&slot0[(size_t)(hint % VG_STATS_REPLICAS) * rep_stride], v);
+    return;
+  }
+#pragma unroll 1
+  for (int k = 0; k < 3 && v != 0.0; ++k) {
+    const float f = (float)v;
+    v -= (double)f;
+    int e;
+    const float m = frexpf(f, &e);               // f = m * 2^e, |m| in [0.5, 1)
+    const int E = e - 24 + 150;                  // f = (m * 2^24) * 2^(E - 150)
+    if (E < 0 || f == 0.f) continue;
+    const long long M = (long long)(m * 16777216.f);
+    const int b = E / 24, sh = E - b * 24;
+    const int rep = b + VG_DET_BINS * (int)(hint & 1u);
+    atomicAdd((unsigned long long*)&slot0[(size_t)rep * rep_stride], (unsigned long long)(M << sh));
+  }
+}
+__device__ inline double vg_acc_read(const double* slot0, size_t rep_stride, int det) {
+  double s = 0.0;
+  if (!det) {
+    for (int r = 0; r < VG_STATS_REPLICAS; ++r) s += slot0[(size_t)r * rep_stride];
+    return s;
+  }
+  const long long* q = (const long long*)slot0;
+  for (int b = VG_DET_BINS - 1; b >= 0; --b) {
+    const long long t = q[(size_t)b * rep_stride] + q[(size_t)(b + VG_DET_BINS) * rep_stride];
+    s += ldexp((double)t, 24 * b - 150);
+  }
+  return s;
+}
+// the [VG_STATS_REPLICAS][2][cpad] layout of the BatchNorm sums (which: 0 = first sum, 1 = second)
+__device__ inline void vg_stats_add(double* stats, int cpad, int which, int ch, unsigned hint, double v, int det) {
+  vg_acc_add(stats + (size_t)which * cpad + ch, (size_t)2 * cpad, hint, v, det);
+}
+__device__ inline double vg_stats_read(const double* stats, int cpad, int which, int ch, int det) {
+  return vg_acc_read(stats + (size_t)which * cpad + ch, (size_t)2 * cpad, det);
+}
+
 __device__ inline float vg_lrelu(float x) { return x > 0.f ? x : x * VG_LRELU_SLOPE; }
 __device__ inline float vg_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 

@@ -58,6 +58,7 @@ struct IgemmParams {
   // layout as y; bs_y = its output when the activation mask has to come from there (residual BatchNorm), else the mask
   // is recomputed as x*scale+shift > 0 like the forward pass did.
   vg_bn_bwd_stats bs;
+  int det;                // statistics through the fixed-point accumulators (common.h: vg_stats_add)
 };
 
 static void pack_taps(IgemmParams& p) {
@@ -314,9 +315,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
-    const int rep = (mtile + phase) % VG_STATS_REPLICAS;
-    unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.Npad + n0 + tid], (double)t1);
-    unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + n0 + tid], (double)t2);
+    vg_stats_add(p.stats, p.Npad, 0, n0 + tid, mtile + phase, (double)t1, p.det);
+    vg_stats_add(p.stats, p.Npad, 1, n0 + tid, mtile + phase, (double)t2, p.det);
   }
   T* __restrict__ yg = (T*)p.y;
   constexpr int PPR = BN / PIECE;
@@ -573,9 +573,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm2_kernel(const IgemmParams 
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
-    const int rep = (mtile + phase) % VG_STATS_REPLICAS;
-    unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.Npad + n0 + tid], (double)t1);
-    unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + n0 + tid], (double)t2);
+    vg_stats_add(p.stats, p.Npad, 0, n0 + tid, mtile + phase, (double)t1, p.det);
+    vg_stats_add(p.stats, p.Npad, 1, n0 + tid, mtile + phase, (double)t2, p.det);
   }
   T* __restrict__ yg = (T*)p.y;
   constexpr int PPR = WN_COLS / PIECE;
@@ -1094,9 +1093,8 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
-      const int rep = (mtile + phase) % VG_STATS_REPLICAS;
-      unsafeAtomicAdd(&p.bs.sums[((size_t)rep * 2 + 0) * p.bs.cpad + n0 + tid], (double)t1);
-      unsafeAtomicAdd(&p.bs.sums[((size_t)rep * 2 + 1) * p.bs.cpad + n0 + tid], (double)t2);
+      vg_stats_add(p.bs.sums, p.bs.cpad, 0, n0 + tid, mtile + phase, (double)t1, p.det);
+      vg_stats_add(p.bs.sums, p.bs.cpad, 1, n0 + tid, mtile + phase, (double)t2, p.det);
     }
     __syncthreads();
   }
@@ -1117,9 +1115,8 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
-      const int rep = (mtile + phase) % VG_STATS_REPLICAS;
-      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.Npad + n0 + tid], (double)t1);
-      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + n0 + tid], (double)t2);
+      vg_stats_add(p.stats, p.Npad, 0, n0 + tid, mtile + phase, (double)t1, p.det);
+      vg_stats_add(p.stats, p.Npad, 1, n0 + tid, mtile + phase, (double)t2, p.det);
     }
   }
   VG_STAMP(4);
@@ -1556,9 +1553,8 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
       double t1 = 0.0, t2 = 0.0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
-      const int rep = (blockIdx.x + phase) % VG_STATS_REPLICAS;
-      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.Npad + tid], t1);
-      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.Npad + tid], t2);
+      vg_stats_add(p.stats, p.Npad, 0, tid, blockIdx.x + phase, t1, p.det);
+      vg_stats_add(p.stats, p.Npad, 1, tid, blockIdx.x + phase, t2, p.det);
     }
   }
 }
@@ -1764,6 +1760,7 @@ static int conv_fwd_impl(const vg_conv_desc* d, const void* x, const void* w_pac
   VG_REQUIRE(x && w_packed && y, "conv_fwd: null pointer");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
+  p.det = vg_det_mode();
   if (fused) *fused = 0;
   if (bs) {
     rc = check_bs(bs, d->co);
@@ -1828,6 +1825,7 @@ extern "C" int vg_conv_fwd_splitk(const vg_conv_desc* d, const void* x, const vo
   hipStream_t st = (hipStream_t)stream;
   IgemmParams p;
   memset(&p, 0, sizeof(p));
+  p.det = vg_det_mode();
   p.x = x; p.w = w_packed; p.bias = nullptr; p.y = y; p.stats = nullptr;
   p.N = d->n; p.H = d->h; p.W = d->w; p.C = cpad_of(d->ci, d->dtype); p.Cs = d->xcs;
   p.OHl = d->oh; p.OWl = d->ow; p.OH = d->oh; p.OW = d->ow; p.Ks = d->ycs;
@@ -1842,6 +1840,7 @@ extern "C" int vg_conv_fwd_splitk(const vg_conv_desc* d, const void* x, const vo
     ksplit = (int)vg_ceil_div(512, tiles);
   }
   if (ksplit > nk / 8) ksplit = nk / 8;
+  if (vg_det_mode()) ksplit = 1;      // the slices meet in f32 atomics: reproducible runs do not split
   if (ksplit < 1) ksplit = 1;
   if (ksplit > 65535) ksplit = 65535;
   p.ksplit = ksplit; p.splitws = (float*)ws; p.act = VG_ACT_NONE;
@@ -1870,6 +1869,7 @@ static int conv_dgrad_impl(const vg_conv_desc* d, const void* dy, const void* w_
   VG_REQUIRE(d->h % s == 0 && d->w % s == 0, "conv_dgrad: input %dx%d not a multiple of stride %d", d->h, d->w, s);
   IgemmParams p;
   memset(&p, 0, sizeof(p));
+  p.det = vg_det_mode();
   if (fused) *fused = 0;
   if (bs) {
     rc = check_bs(bs, d->ci);
@@ -1921,6 +1921,7 @@ struct WgradParams {
   signed char dy_[VG_MAX_TAPS];
   signed char dx_[VG_MAX_TAPS];
   int dbg;              // timing ablations only (VG_ABLATE build): 16 = one B fragment for all taps, 32 = no in-loop DMA, 64 = no barrier
+  int det;              // reproducible accumulation (vg_set_deterministic): one pixel split, waves add in order
   size_t part_elems;    // spatial-tile kernels: dw is [groups * KS][part_elems] partial images, written with plain stores
 };
 
@@ -2096,18 +2097,26 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
   // acc[i][j][r]: row (o) = (r&3) + 8*(r>>2) + 4*h, column (c) = l32
   const size_t rowstride = (size_t)p.ntaps * p.Cpad;
+  // p.det (one pixel split per dW tile, so only the WK waves of this block meet on an element): the waves add in wave
+  // order (their atomics are performed at the L2 before the barrier lets the next wave go): the same bits on every run
+  for (int turn = 0; turn < (p.det ? WK : 1); ++turn) {
+    if (!p.det || wk == turn) {
 #pragma unroll
-  for (int i = 0; i < OI; ++i)
+      for (int i = 0; i < OI; ++i)
 #pragma unroll
-    for (int j = 0; j < CI; ++j) {
-      const int c = c0 + (wc * CI + j) * 32 + l32;
-      if (c >= p.Cpad) continue;
+        for (int j = 0; j < CI; ++j) {
+          const int c = c0 + (wc * CI + j) * 32 + l32;
+          if (c >= p.Cpad) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + (wo * OI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (o < p.Opad) unsafeAtomicAdd(&p.dw[(size_t)o * rowstride + (size_t)tap * p.Cpad + c], acc[i][j][r]);
-      }
+          for (int r = 0; r < 16; ++r) {
+            const int o = o0 + (wo * OI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (o >= p.Opad) continue;
+            unsafeAtomicAdd(&p.dw[(size_t)o * rowstride + (size_t)tap * p.Cpad + c], acc[i][j][r]);
+          }
+        }
     }
+    if (p.det && WK > 1) { __threadfence(); __syncthreads(); }
+  }
 }
 
 template <typename T, int OI, int CI, int WO, int WC, int WK>
@@ -2123,6 +2132,8 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t st) {
   int splits = (int)vg_ceil_div(1024, base_blocks);        // aim for ~4 blocks per CU
   const int min_chunks = 8;
   if (splits > p.nchunks / min_chunks) splits = p.nchunks / min_chunks;
+  p.det = vg_det_mode();
+  if (p.det) splits = 1;              // pixel splits meet in f32 atomics: reproducible runs keep one block per dW tile
   if (splits < 1) splits = 1;
   p.chunks_per_split = (int)vg_ceil_div(p.nchunks, splits);
   splits = (int)vg_ceil_div(p.nchunks, p.chunks_per_split);

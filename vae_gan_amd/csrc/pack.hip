@@ -238,12 +238,22 @@ extern "C" int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Library-wide reproducibility switch (vg_api.h: vg_set_deterministic).  Read by every launcher that accumulates
+// across blocks: statistics go through the fixed-point accumulators of common.h, kernels that split a reduction
+// over blocks with f32 atomics run unsplit or on an ordered variant.
+// ---------------------------------------------------------------------------------------------
+static int g_det_mode = 0;
+int vg_det_mode(void) { return g_det_mode; }
+extern "C" void vg_set_deterministic(int on) { g_det_mode = on ? 1 : 0; }
+extern "C" int vg_get_deterministic(void) { return g_det_mode; }
+
+// ---------------------------------------------------------------------------------------------
 // per-channel column sum (bias gradients): out[c] = sum_m a[m][c]
 // thread = one 16-byte piece column over a strided set of rows; the block folds its row groups
 // through LDS and issues ONE f64 atomic per channel into one of VG_STATS_REPLICAS copies.
 // ---------------------------------------------------------------------------------------------
 template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ a, int64_t rows, int cs,
-                                                                                double* __restrict__ ws) {
+                                                                                double* __restrict__ ws, int det) {
   constexpr int PIECE = Elt<T>::PIECE;
   __shared__ float red[256 * PIECE];
   const int ppr = cs / PIECE;
@@ -270,25 +280,27 @@ template <typename T> __global__ __launch_bounds__(256) void channel_sum_kernel(
     for (int e = 0; e < PIECE; ++e) red[rr * cs + pc * PIECE + e] = (float)(dacc[e] + (double)acc[e]);
   }
   __syncthreads();
-  const int rep = blockIdx.x % VG_STATS_REPLICAS;
   for (int ch = threadIdx.x; ch < cs; ch += 256) {
     double t = 0.0;
     for (int r = 0; r < rpb; ++r) t += red[r * cs + ch];
-    unsafeAtomicAdd(&ws[(size_t)rep * cs + ch], t);
+    vg_acc_add(ws + ch, cs, blockIdx.x, t, det);
   }
 }
 
+// det (only with replicas == VG_STATS_REPLICAS): the slots are the fixed-point bins of vg_acc_add
 __global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, int n, double scale, int replicas,
-                           int stride, int accumulate) {
+                           int stride, int accumulate, int det) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   double t = 0.0;
-  for (int r = 0; r < replicas; ++r) t += src[(size_t)r * stride + i];
+  if (det) t = vg_acc_read(src + i, stride, 1);
+  else
+    for (int r = 0; r < replicas; ++r) t += src[(size_t)r * stride + i];
   dst[i] = accumulate ? dst[i] + (float)(t * scale) : (float)(t * scale);
 }
 
 // 4-channel bf16 rows (the thin image-side layout): a thread walks pixels, 8-byte loads
-__global__ __launch_bounds__(256) void channel_sum4_kernel(const bf16_t* __restrict__ a, int64_t rows, double* __restrict__ ws) {
+__global__ __launch_bounds__(256) void channel_sum4_kernel(const bf16_t* __restrict__ a, int64_t rows, double* __restrict__ ws, int det) {
   __shared__ float red[4][4];
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   double dacc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -311,7 +323,7 @@ __global__ __launch_bounds__(256) void channel_sum4_kernel(const bf16_t* __restr
   __syncthreads();
   if (threadIdx.x < 4) {
     const int e = threadIdx.x;
-    unsafeAtomicAdd(&ws[(size_t)(blockIdx.x % VG_STATS_REPLICAS) * 4 + e], (double)((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])));
+    vg_acc_add(ws + e, 4, blockIdx.x, (double)((red[0][e] + red[1][e]) + (red[2][e] + red[3][e])), det);
   }
 }
 
@@ -323,9 +335,9 @@ extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, 
     VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 4 * VG_STATS_REPLICAS, st4));
     int blocks = (int)vg_ceil_div(rows, 256 * 16);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(channel_sum4_kernel, dim3(blocks), dim3(256), 0, st4, (const bf16_t*)a, rows, ws);
+    hipLaunchKernelGGL(channel_sum4_kernel, dim3(blocks), dim3(256), 0, st4, (const bf16_t*)a, rows, ws, vg_det_mode());
     VG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, st4, (const double*)ws, out, c_valid, 1.0, VG_STATS_REPLICAS, 4, accumulate);
+    hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, st4, (const double*)ws, out, c_valid, 1.0, VG_STATS_REPLICAS, 4, accumulate, vg_det_mode());
     VG_LAUNCH_CHECK();
     return VG_OK;
   }
@@ -337,11 +349,11 @@ extern "C" int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, 
   int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 16);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, rows, cs, ws);
-  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws);
+  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, rows, cs, ws, vg_det_mode());
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws, vg_det_mode());
   VG_LAUNCH_CHECK();
   hipLaunchKernelGGL(d2f_kernel, dim3((c_valid + 255) / 256), dim3(256), 0, st, (const double*)ws, out, c_valid, 1.0,
-                     VG_STATS_REPLICAS, cs, accumulate);
+                     VG_STATS_REPLICAS, cs, accumulate, vg_det_mode());
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -393,18 +405,18 @@ extern "C" int vg_channel_sum_noalloc(const void* a, int64_t rows, int cs, int c
   int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 16);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, rows, cs, ws);
-  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws);
+  if (dtype == VG_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, rows, cs, ws, vg_det_mode());
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, rows, cs, ws, vg_det_mode());
   VG_LAUNCH_CHECK();
   hipLaunchKernelGGL(d2f_kernel, dim3((c_valid + 255) / 256), dim3(256), 0, st, (const double*)ws, out, c_valid, 1.0,
-                     VG_STATS_REPLICAS, cs, accumulate);
+                     VG_STATS_REPLICAS, cs, accumulate, vg_det_mode());
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
 
 extern "C" int vg_scalar_finish(const double* src, double scale, float* dst, void* stream) {
   VG_REQUIRE(src && dst, "scalar_finish: null pointer");
-  hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, dst, 1, scale, 1, 0, 0);
+  hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, dst, 1, scale, 1, 0, 0, 0);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }

@@ -24,6 +24,7 @@ struct ThinParams {
   const float* w;       // master weight [O][I][R][R]
   const float* bias;
   double* stats;        // thin->wide forward: [VG_STATS_REPLICAS][2][cpad]
+  int det;              // statistics through the fixed-point accumulators (common.h: vg_stats_add)
   float* part;          // weight gradient: [blocks][64][64] partial images
   const bf16_t* wpk;    // packed [64][72] weight image (thin_pack_kernel)
   int N, TH_, TW_, WH, WW, Ws;
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinParams p) {
       const float t1 = (red[0][tid][0] + red[1][tid][0]) + (red[2][tid][0] + red[3][tid][0]);
       const float t2 = (red[0][tid][1] + red[1][tid][1]) + (red[2][tid][1] + red[3][tid][1]);
       const int rep = blockIdx.x % VG_STATS_REPLICAS;
-      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 0) * p.cpad + tid], (double)t1);
-      unsafeAtomicAdd(&p.stats[((size_t)rep * 2 + 1) * p.cpad + tid], (double)t2);
+      vg_stats_add(p.stats, p.cpad, 0, tid, rep, (double)t1, p.det);
+      vg_stats_add(p.stats, p.cpad, 1, tid, rep, (double)t2, p.det);
     }
   }
 }
@@ -463,7 +464,7 @@ extern "C" int vg_thin_conv_fwd(const vg_conv_desc* d, const void* x, const floa
   hipLaunchKernelGGL(thin_pack_kernel, dim3(1), dim3(256), 0, st, p, (bf16_t*)ws, kind == 1 ? 1 : 0);
   VG_LAUNCH_CHECK();
   if (kind == 1) {
-    p.thin = (const bf16_t*)x; p.stats = stats; p.cpad = d->co <= 32 ? 32 : 64;
+    p.thin = (const bf16_t*)x; p.stats = stats; p.cpad = d->co <= 32 ? 32 : 64; p.det = vg_det_mode();
     thin_tiles(p, p.WH, p.WW, 8, 32);
     if (d->r == 3) hipLaunchKernelGGL((thin_in_kernel<3, 1>), dim3(p.ntiles), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((thin_in_kernel<4, 2>), dim3(p.ntiles), dim3(256), 0, st, p);

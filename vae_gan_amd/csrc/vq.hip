@@ -225,7 +225,7 @@ extern "C" int vg_vq_assign(const float* z, const float* codebook, int64_t rows,
 __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                         const int64_t* __restrict__ idx, int64_t rows, int K, int D,
                                                         float* __restrict__ zq, double* __restrict__ sse,
-                                                        float* __restrict__ counts, float* __restrict__ esum) {
+                                                        float* __restrict__ counts, float* __restrict__ esum, int det) {
   const int tpr = D / 4;                       // threads per row
   const int rpb = 256 / tpr;
   const int c4 = threadIdx.x % tpr, rr = threadIdx.x / tpr;
@@ -246,9 +246,11 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
       }
       *(f32x4*)(zq + (size_t)r * D + c4 * 4) = o;
       if (esum != nullptr) {
+        if (!det) {        // det: vq_esum_ordered_kernel
 #pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&esum[(size_t)code * D + c4 * 4 + e], zv[e]);
-        if (c4 == 0) unsafeAtomicAdd(&counts[code], 1.0f);
+          for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&esum[(size_t)code * D + c4 * 4 + e], zv[e]);
+        }
+        if (c4 == 0) unsafeAtomicAdd(&counts[code], 1.0f);     // whole numbers below 2^24: exact in any order
       }
     }
   }
@@ -312,13 +314,48 @@ __global__ __launch_bounds__(1024) void vq_gather_lds_kernel(const float* __rest
   }
 }
 
+// Reproducible EMA sums (vg_set_deterministic): one block per code walks the assignment in row order; a wave owns a
+// quarter of the rows, finds its code's rows 64 at a time (ballot) and adds them in ascending order, one lane per
+// channel; the four quarter sums are combined in a fixed order.  K blocks re-read idx (rows * 8 bytes each, from L2).
+__global__ __launch_bounds__(256) void vq_esum_ordered_kernel(const float* __restrict__ z, const int64_t* __restrict__ idx,
+                                                              int64_t rows, int K, int D, float* __restrict__ esum) {
+  constexpr int MAXJ = 16;                     // D <= 1024
+  __shared__ float part[4][1024];
+  const int code = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) acc[j] = 0.f;
+  const int64_t q = (rows + 3) / 4;
+  const int64_t r1 = min(rows, (int64_t)(wave + 1) * q);
+  for (int64_t r0 = (int64_t)wave * q; r0 < r1; r0 += 64) {
+    const int64_t r = r0 + lane;
+    int c = r < r1 ? (int)idx[r] : -1;
+    if (r < r1) { if (c < 0) c = 0; if (c >= K) c = K - 1; }
+    unsigned long long m = __ballot(c == code);
+    while (m) {
+      const int bit = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const float* zr = z + (size_t)(r0 + bit) * D;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j)
+        if (lane + 64 * j < D) acc[j] += zr[lane + 64 * j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j)
+    if (lane + 64 * j < D) part[wave][lane + 64 * j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) esum[(size_t)code * D + c] += (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
+
 extern "C" int vg_vq_gather(const float* z, const float* codebook, const int64_t* idx, int64_t rows, int k, int d,
                             float* zq, double* sse, float* counts, float* esum, void* stream) {
   VG_REQUIRE(z && codebook && idx && zq && rows > 0 && k > 0, "vq_gather: bad arguments");
   VG_REQUIRE(d % 4 == 0 && d / 4 <= 256, "vq_gather: embedding_dim %d unsupported", d);
   VG_REQUIRE((counts == nullptr) == (esum == nullptr), "vq_gather: counts and esum must be given together");
   const size_t lds = sizeof(float) * ((size_t)k * d + k);
-  if (esum != nullptr && lds <= 144 * 1024 && rows >= 8192) {
+  const int det = vg_det_mode();
+  if (esum != nullptr && lds <= 144 * 1024 && rows >= 8192 && !det) {
     VG_HIP(hipFuncSetAttribute((const void*)vq_gather_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     const int rpb1 = 1024 / (d / 4);
     int64_t nb = vg_ceil_div(rows, (int64_t)rpb1 * 16);        // >= 16 rows per thread before a block pays its flush
@@ -332,8 +369,12 @@ extern "C" int vg_vq_gather(const float* z, const float* codebook, const int64_t
   int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 4);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(vq_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, z, codebook, idx, rows, k,
-                     d, zq, sse, counts, esum);
+                     d, zq, sse, counts, esum, det);
   VG_LAUNCH_CHECK();
+  if (det && esum != nullptr) {
+    hipLaunchKernelGGL(vq_esum_ordered_kernel, dim3((unsigned)k), dim3(256), 0, (hipStream_t)stream, z, idx, rows, k, d, esum);
+    VG_LAUNCH_CHECK();
+  }
   return VG_OK;
 }
 

@@ -23,9 +23,23 @@ _COMPUTE_DTYPE = [torch.bfloat16]
 
 
 def set_compute_dtype(dt: torch.dtype) -> None:
-    """bf16 (MFMA bf16, the benchmarked mode) or f32 (exact-f32 MFMA, the parity mode)."""
+    """bf16 (MFMA bf16, the benchmarked mode) or f32 (exact-f32 MFMA, the parity mode).
+
+    The f32 mode is also the reproducible one: it turns ``vg_set_deterministic`` on (statistics through fixed-point
+    accumulators, no f32 atomics between blocks), so two runs of the same step give the same bits.  ``VG_DETERMINISTIC=1``
+    asks for that in bf16 too (a few per cent slower), ``VG_DETERMINISTIC=0`` keeps the f32 mode on the faster atomics."""
     L.vg_dtype(dt)
     _COMPUTE_DTYPE[0] = dt
+    env = _os.environ.get("VG_DETERMINISTIC")
+    set_deterministic(dt == torch.float32 if env is None else env not in ("0", ""))
+
+
+def set_deterministic(on: bool) -> None:
+    L.load().vg_set_deterministic(1 if on else 0)
+
+
+def deterministic() -> bool:
+    return bool(L.load().vg_get_deterministic())
 
 
 def compute_dtype() -> torch.dtype:

@@ -69,6 +69,8 @@ class DataParallel:
 
     # ---- global-batch statistics (ops.STAT_SYNC interface)
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype == torch.float64 and ops.deterministic():
+            t = t.view(torch.int64)      # statistics buffers hold fixed-point bins (vg_api.h: vg_set_deterministic)
         if self.world > 1:
             if self._staged and t.is_cuda:
                 h = t.cpu()
