@@ -147,3 +147,37 @@ def test_dgrad_bnstats_reports_unfused_kernels(gpu):
                                       L.stream()), "dgrad_bnstats")
     torch.cuda.synchronize()
     assert fused.value == 0 and float(sums.abs().max()) == 0.0 and torch.isfinite(dx.float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_batched_repack_matches_single_pack(gpu, dtype):
+    """vg_conv_pack_batch (one launch for every packed image of an optimizer) writes the same bits as vg_conv_pack_weight,
+    padding included: plain and transposed images, 3x3 / 4x4 stride 2 (four phases of 2x2 taps) / 1x1 / 4x4 stride 1,
+    thin and ragged channel counts."""
+    import ctypes as C
+    import numpy as np
+    from vae_gan_amd import lib as L
+    lib = L.load()
+    geos = [(64, 64, 3, 1, 1), (128, 64, 4, 2, 1), (3, 64, 3, 1, 1), (64, 3, 3, 1, 1), (512, 64, 1, 1, 0), (512, 1, 4, 1, 1),
+            (320, 128, 3, 1, 1), (96, 40, 4, 2, 1), (512, 512, 3, 1, 1)]
+    isz = lib.vg_conv_pack_item_bytes()
+    table = np.zeros(len(geos) * 2 * isz, dtype=np.uint8)
+    keep, want, got = [], [], []
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    for k_, (ci, co, k, stride, pad) in enumerate(geos):
+        d = G.make_desc(1, 16, 16, ci, co, k, stride, pad, dtype)
+        w = torch.randn(co, ci, k, k, device="cuda", generator=gen)
+        keep.append((d, w))
+        for tr in (0, 1):
+            want.append(G.pack(lib, d, w, tr, dtype))
+            buf = torch.full_like(want[-1], float("nan"))
+            got.append(buf)
+            item = (C.c_uint8 * isz)()
+            L.check(lib.vg_conv_pack_item(C.byref(d), tr, w.data_ptr(), buf.data_ptr(), item), "pack_item")
+            table[(2 * k_ + tr) * isz:(2 * k_ + tr + 1) * isz] = np.frombuffer(item, dtype=np.uint8)
+    dev = torch.from_numpy(table).cuda()
+    L.check(lib.vg_conv_pack_batch(dev.data_ptr(), len(got), L.VG_BF16 if dtype == torch.bfloat16 else L.VG_F32, L.stream()), "pack_batch")
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                           b.view(torch.int16 if dtype == torch.bfloat16 else torch.int32)), (geos[i // 2], i % 2)

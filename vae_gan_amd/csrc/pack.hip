@@ -96,25 +96,40 @@ extern "C" int vg_conv_pack_weight(const vg_conv_desc* d, int transposed, const 
 // ---- batched re-pack: every packed weight image of one optimizer in ONE launch after its step (a training step
 // re-packs ~60 images; as separate 7 us launches that was 0.43 ms of a 44 ms step).  The caller keeps a table of
 // PackParams in device memory (vg_conv_pack_item fills one on the host); block (x, y) works on item y.
+// A block takes 32 x 32 (n, c) entries of the packed image with all their taps: it reads the matching 32 rows of
+// 32 * RS consecutive master weights (coalesced; the packed order would read every RS-th float), turns them in LDS and
+// writes, per phase and tap, 32 rows of 32 consecutive packed elements.  Padding rows / columns are written as zeros.
 template <typename T> __global__ __launch_bounds__(256) void pack_batch_kernel(const PackParams* __restrict__ items) {
+  extern __shared__ float tile[];                      // [32][32 * bs + 1], bs = RS | 1 (odd strides: no bank conflicts)
   const PackParams& p = items[blockIdx.y];
-  const long total = (long)p.nphases * p.Npad * p.ntaps * p.Cpad;
+  const int RS = p.RS, bs = RS | 1, rowf = 32 * bs + 1;
+  const int A = p.O, B = p.I;                           // master weights [A][B][RS]
+  const int ctiles = (p.Cpad + 31) / 32, ntiles = ((p.Npad + 31) / 32) * ctiles;
   T* out = (T*)p.out;
-  for (long t = blockIdx.x * 256L + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    int c = (int)(t % p.Cpad);
-    long r1 = t / p.Cpad;
-    int tap = (int)(r1 % p.ntaps);
-    long r2 = r1 / p.ntaps;
-    int n = (int)(r2 % p.Npad);
-    int ph = (int)(r2 / p.Npad);
-    int rs = p.rs[ph][tap];
-    float v = 0.f;
-    if (!p.transposed) {
-      if (n < p.O && c < p.I) v = p.w[((size_t)n * p.I + c) * p.RS + rs];
-    } else {
-      if (n < p.I && c < p.O) v = p.w[((size_t)c * p.I + n) * p.RS + rs];
+  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int n0 = (t / ctiles) * 32, c0 = (t % ctiles) * 32;
+    const int a0 = p.transposed ? c0 : n0, b0 = p.transposed ? n0 : c0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 32 * RS; i += 256) {
+      const int a = i / (32 * RS), rem = i - a * (32 * RS);
+      const int b = rem / RS, rs = rem - b * RS;
+      float v = 0.f;
+      if (a0 + a < A && b0 + b < B) v = p.w[((size_t)(a0 + a) * B + b0) * RS + rem];
+      tile[a * rowf + b * bs + rs] = v;
     }
-    out[t] = Elt<T>::from_f(v);
+    __syncthreads();
+    for (int ph = 0; ph < p.nphases; ++ph)
+      for (int tap = 0; tap < p.ntaps; ++tap) {
+        const int rs = p.rs[ph][tap];
+#pragma unroll
+        for (int r = grp; r < 32; r += 8) {             // r: row of the packed tile (n), lane32: its column (c)
+          const int n = n0 + r, c = c0 + lane32;
+          if (n >= p.Npad || c >= p.Cpad) continue;
+          const float v = p.transposed ? tile[lane32 * rowf + r * bs + rs] : tile[r * rowf + lane32 * bs + rs];
+          out[(((size_t)ph * p.Npad + n) * p.ntaps + tap) * p.Cpad + c] = Elt<T>::from_f(v);
+        }
+      }
   }
 }
 
@@ -133,9 +148,16 @@ extern "C" int vg_conv_pack_item(const vg_conv_desc* d, int transposed, const fl
 extern "C" int vg_conv_pack_batch(const void* items_dev, int n_items, int dtype, void* stream) {
   VG_REQUIRE(items_dev && n_items > 0 && n_items <= 65535, "pack_batch: bad arguments");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "pack_batch: bad dtype %d", dtype);
-  dim3 grid(64, n_items);
-  if (dtype == VG_BF16) hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const PackParams*)items_dev);
-  else hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackParams*)items_dev);
+  dim3 grid(256, n_items);                               // a block per 32 x 32 tile: 512 x 512 channels = 256 tiles
+  const size_t lds = (size_t)32 * (32 * 17 + 1) * sizeof(float);      // RS <= 16
+  static bool attr_set = false;
+  if (!attr_set) {
+    VG_HIP(hipFuncSetAttribute((const void*)pack_batch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    VG_HIP(hipFuncSetAttribute((const void*)pack_batch_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (dtype == VG_BF16) hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const PackParams*)items_dev);
+  else hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const PackParams*)items_dev);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
