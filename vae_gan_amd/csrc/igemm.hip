@@ -1255,10 +1255,15 @@ static bool g_conv_kernel_is_old() { return g_conv_kernel < 3; }
 #ifndef VG_IGEMM4_PD
 #define VG_IGEMM4_PD 2
 #endif
-template <int R, int S, int CCH>
+// PH ("a phase per wave"): stride-2 transposed gathers (transposed convolutions, input gradients of stride-2
+// convolutions) = four output phases (py, px) of 2x2 taps over the same input pixels.  The four waves of a block take
+// one phase each, with that phase's 2x2 x C x 64 weights in registers, over the SAME 2 x 32 input pixel tile: one halo
+// image (tile + one pixel all round) serves all four phases, where one launch dimension per phase fetched it four times.
+template <int R, int S, int CCH, bool PH>
 struct Igemm4Cfg {
-  static constexpr int NT = 256, TW = 32, TH = 8, BM = TH * TW, BN = 64;
-  static constexpr int NTAPS = R * S, HS = 35, HSB = HS * 64, HH = TH + R - 1;
+  static constexpr int NT = 256, TW = 32, TH = PH ? 2 : 8, BM = TH * TW, BN = 64;
+  static constexpr int NTAPS = R * S, HS = 35, HSB = HS * 64, HH = TH + (PH ? 2 : R - 1);
+  static constexpr int WCOLS = TW + (PH ? 2 : S - 1);           // halo columns that are read
   static constexpr int CHB = HH * HSB;                          // one channel chunk of a halo image
   static constexpr int NPIECE = CCH * HH * HS * 4;              // 16-byte pieces per tile
   static constexpr int HRN = (NPIECE + NT - 1) / NT;            // DMA rounds per tile
@@ -1271,9 +1276,10 @@ struct Igemm4Cfg {
   static constexpr bool FITS = LDS <= 160 * 1024 && NTAPS * CCH * 16 <= 320 && 4 * BN * 2 * 8 <= 4 * WTILE;
 };
 
-template <int R, int S, int CCH, bool LR, bool ST, bool ACC>
+template <int R, int S, int CCH, bool LR, bool ST, bool ACC, bool PH>
 __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
-  typedef Igemm4Cfg<R, S, CCH> Cfg;
+  typedef Igemm4Cfg<R, S, CCH, PH> Cfg;
+  static_assert(!PH || (R == 2 && S == 2 && !ACC), "a phase per wave: 2x2 taps, plain stores");
   typedef bf16_t T;
   constexpr int NT = Cfg::NT, TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, NTAPS = Cfg::NTAPS;
   constexpr int HS = Cfg::HS, HSB = Cfg::HSB, HH = Cfg::HH, CHB = Cfg::CHB, HRN = Cfg::HRN, HBYTES = Cfg::HBYTES;
@@ -1283,12 +1289,19 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = pixel-row pair of the tile
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = pixel-row pair of the tile, or (PH) the phase
   const int h = lane >> 5, l32 = lane & 31;
-  const int phase = blockIdx.y;
+  const int phase = PH ? wave : (int)blockIdx.y;
   const int py = phase / p.out_s, px = phase % p.out_s;
   const int tpi = p.tilesX * p.tilesY;
-  const int dymin = p.dymin_i[phase], dxmin = p.dxmin_i[phase];
+  // origin of the halo image relative to the tile: the smallest tap offset (PH: over all four phases)
+  int dymin = p.dymin_i[phase], dxmin = p.dxmin_i[phase];
+  if (PH) {
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) { dymin = min(dymin, p.dymin_i[ph]); dxmin = min(dxmin, p.dxmin_i[ph]); }
+  }
+  const int rowoff = (PH ? 0 : 2 * wave) + (p.dymin_i[phase] - dymin);     // halo row of this wave's first tap, first pixel row
+  const int coloff = p.dxmin_i[phase] - dxmin;
   const bool flip = p.flip != 0;
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
   const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
@@ -1320,7 +1333,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     const int cc = q / (HH * HS * 4), rem = q - cc * (HH * HS * 4);
     const int pix = rem >> 2, ps = rem & 3;
     const int hy = pix / HS, hx = pix - hy * HS;
-    const bool ok = q < Cfg::NPIECE && hx < TW + S - 1;
+    const bool ok = q < Cfg::NPIECE && hx < Cfg::WCOLS;
     ptab[rd * NT] = i32x2{((hy * p.W + hx) * p.Cs) * 2 + cc * 64 + (((ps ^ (hx >> 2)) & 3) << 4), ok ? ((hy << 8) | hx) : -1};
   }
   // tile k of this block: with the full grid of 256 blocks, the 32 blocks of an XCD (blockIdx % 8) take 32 consecutive tiles
@@ -1336,8 +1349,8 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   int ct[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int hx = l32 + (flip ? S - 1 - s : s);
-    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4) + 2 * wave * HSB;
+    const int hx = l32 + (flip ? S - 1 - s : s) + coloff;
+    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4) + rowoff * HSB;
   }
   float bv[2];
 #pragma unroll
@@ -1373,7 +1386,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     return *(const u32x4*)(wt + (sidx >> 2) * 32 * WSTRIDE + ((lane + 64 * (sidx & 3)) >> 3) * WSTRIDE + (lane & 7) * PIECE);
   };
   T* pdst = nullptr;                          // previous tile: first output row of this wave, this lane's piece
-  auto store_ptr = [&](int sidx) { return pdst + (size_t)(sidx >> 2) * p.OW * BN + (sidx & 3) * 512; };
+  auto store_ptr = [&](int sidx) { return pdst + (size_t)(sidx >> 2) * p.out_s * p.OW * BN + (sidx & 3) * 8 * p.out_s * BN; };
   auto store_piece = [&](int sidx, u32x4 v, u32x4 old) {
     if (ACC) {               // y += conv: bf16(bf16(conv) + y), the rounding order of the other kernels' read-modify-write
       Piece<T> o, q;
@@ -1510,7 +1523,8 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    pdst = yg + ((((size_t)img * p.OH + ty0 + 2 * wave) * p.OW + tx0) * BN + lane * PIECE);
+    pdst = yg + ((((size_t)img * p.OH + (ty0 + (PH ? 0 : 2 * wave)) * p.out_s + py) * p.OW + tx0 * p.out_s + px) * BN +
+                 (lane >> 3) * p.out_s * BN + (lane & 7) * PIECE);
     has_prev = !VG_DBG4(64);
     // halo rounds and stores were issued in the first 2/3 of the K loop: (nearly) free by now, and it makes the barrier
     // at the top of the next iteration mean "the next halo is in LDS"
@@ -1559,29 +1573,38 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   }
 }
 
-static bool g_igemm4 = true;
-template <int R, int S, int CCH, bool LR, bool ST, bool ACC>
+static bool g_igemm4 = true, g_igemm4p = true;
+template <int R, int S, int CCH, bool LR, bool ST, bool ACC, bool PH>
 static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
-  typedef Igemm4Cfg<R, S, CCH> Cfg;
+  typedef Igemm4Cfg<R, S, CCH, PH> Cfg;
   static_assert(Cfg::FITS, "igemm4 configuration does not fit");
   *handled = false;
   IgemmParams p = p0;
-  int flip = -1;       // the tap grid must be R x S, row-major, offsets all ascending or all descending (as for igemm3)
-  {
+  int flip = -1;       // the tap grid must be R x S, row-major, offsets all ascending or all descending, in every phase
+  for (int ph = 0; ph < p.nphases; ++ph) {
     int ymin = 127, xmin = 127;
     for (int t = 0; t < p.ntaps; ++t) {
-      ymin = p.dy[0][t] < ymin ? p.dy[0][t] : ymin;
-      xmin = p.dx[0][t] < xmin ? p.dx[0][t] : xmin;
+      ymin = p.dy[ph][t] < ymin ? p.dy[ph][t] : ymin;
+      xmin = p.dx[ph][t] < xmin ? p.dx[ph][t] : xmin;
     }
-    p.dymin[0] = (signed char)ymin; p.dxmin[0] = (signed char)xmin;
+    p.dymin[ph] = (signed char)ymin; p.dxmin[ph] = (signed char)xmin;
     bool asc = true, desc = true;
     for (int t = 0; t < p.ntaps; ++t) {
-      const int yo = p.dy[0][t] - ymin, xo = p.dx[0][t] - xmin;
+      const int yo = p.dy[ph][t] - ymin, xo = p.dx[ph][t] - xmin;
       asc = asc && yo == t / S && xo == t % S;
       desc = desc && yo == R - 1 - t / S && xo == S - 1 - t % S;
     }
-    flip = asc ? 0 : (desc ? 1 : -1);
-    if (flip < 0) return VG_OK;
+    const int f = asc ? 0 : (desc ? 1 : -2);
+    if (f < 0 || (flip >= 0 && f != flip)) return VG_OK;
+    flip = f;
+  }
+  if (PH) {            // the four phases together reach one pixel each way: a (TH + 2) x (TW + 2) halo
+    int lo_y = 127, hi_y = -127, lo_x = 127, hi_x = -127;
+    for (int ph = 0; ph < 4; ++ph) {
+      lo_y = p.dymin[ph] < lo_y ? p.dymin[ph] : lo_y; hi_y = p.dymin[ph] > hi_y ? p.dymin[ph] : hi_y;
+      lo_x = p.dxmin[ph] < lo_x ? p.dxmin[ph] : lo_x; hi_x = p.dxmin[ph] > hi_x ? p.dxmin[ph] : hi_x;
+    }
+    if (hi_y - lo_y > 1 || hi_x - lo_x > 1) return VG_OK;
   }
   p.flip = flip;
   if ((size_t)p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31)) return VG_OK;        // piece offsets inside one image are 32-bit
@@ -1593,7 +1616,7 @@ static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
 #ifdef VG_ABLATE
   p.splitws = (float*)g_stamp_buf;
 #endif
-  auto kern = igemm4_kernel<R, S, CCH, LR, ST, ACC>;
+  auto kern = igemm4_kernel<R, S, CCH, LR, ST, ACC, PH>;
   static bool attr_set = false;
   if (!attr_set) {
     VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
@@ -1601,7 +1624,7 @@ static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
   }
   pack_taps(p);
   const int blocks = p.mtiles < 256 ? p.mtiles : 256;    // one persistent block per CU
-  snprintf(g_last_kernel, sizeof g_last_kernel, "igemm4<bf16,%dx%d,%d>", R, S, CCH);
+  snprintf(g_last_kernel, sizeof g_last_kernel, PH ? "igemm4p<bf16,%dx%d,%d>" : "igemm4<bf16,%dx%d,%d>", R, S, CCH);
   hipLaunchKernelGGL(kern, dim3(blocks, 1), dim3(Cfg::NT), Cfg::LDS, st, p);
   VG_LAUNCH_CHECK();
   *handled = true;
@@ -1610,19 +1633,22 @@ static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
 template <typename T> static int dispatch_igemm4(const IgemmParams& p, hipStream_t st, bool* handled) {
   *handled = false;
   if constexpr (sizeof(T) == 2) {
-    // whole 8 x 32 tiles, 64 real output channels at stride 64: everything else stays on igemm3
-    if (!g_igemm4 || g_conv_kernel_is_old() || p.ksplit > 1 || p.in_s != 1 || p.nphases != 1 || p.Npad != 64 || p.Nout != 64 ||
-        p.Ks != 64 || p.out_s != 1 || p.OWl % 32 != 0 || p.OHl % 8 != 0 || (p.act != VG_ACT_NONE && p.act != VG_ACT_LRELU))
+    // whole tiles, 64 real output channels at stride 64: everything else stays on igemm3
+    if (!g_igemm4 || g_conv_kernel_is_old() || p.ksplit > 1 || p.in_s != 1 || p.Npad != 64 || p.Nout != 64 || p.Ks != 64 ||
+        p.OWl % 32 != 0 || (p.act != VG_ACT_NONE && p.act != VG_ACT_LRELU))
       return VG_OK;
-    if (p.ntaps == 9 && p.C == 64) {
-      const bool lr = p.act == VG_ACT_LRELU, st_ = p.stats != nullptr;
+    const bool lr = p.act == VG_ACT_LRELU, st_ = p.stats != nullptr;
+    if (p.nphases == 1 && p.out_s == 1 && p.ntaps == 9 && p.C == 64 && p.OHl % 8 == 0) {
       if (p.accumulate) {      // input gradients onto a parked skip gradient: no activation, no statistics
         if (lr || st_) return VG_OK;
-        return launch_igemm4<3, 3, 2, false, false, true>(p, st, handled);
+        return launch_igemm4<3, 3, 2, false, false, true, false>(p, st, handled);
       }
-      if (lr) return st_ ? launch_igemm4<3, 3, 2, true, true, false>(p, st, handled) : launch_igemm4<3, 3, 2, true, false, false>(p, st, handled);
-      return st_ ? launch_igemm4<3, 3, 2, false, true, false>(p, st, handled) : launch_igemm4<3, 3, 2, false, false, false>(p, st, handled);
+      if (lr) return st_ ? launch_igemm4<3, 3, 2, true, true, false, false>(p, st, handled) : launch_igemm4<3, 3, 2, true, false, false, false>(p, st, handled);
+      return st_ ? launch_igemm4<3, 3, 2, false, true, false, false>(p, st, handled) : launch_igemm4<3, 3, 2, false, false, false, false>(p, st, handled);
     }
+    // 128 -> 64 stride-2 transposed gathers: a phase per wave
+    if (g_igemm4p && p.nphases == 4 && p.out_s == 2 && p.ntaps == 4 && p.C == 128 && p.OHl % 2 == 0 && !p.accumulate && !lr)
+      return st_ ? launch_igemm4<2, 2, 4, false, true, false, true>(p, st, handled) : launch_igemm4<2, 2, 4, false, false, false, true>(p, st, handled);
   }
   return VG_OK;
 }
@@ -1661,6 +1687,7 @@ extern "C" void vg_set_conv_kernel(int version) {
   g_conv_kernel = version & 0x0f;                 // bit 4 (16): stride-2 forward stays on the im2col-row kernel
   g_igemm3_s2 = !(version & 0x10);
   g_igemm4 = !(version & 0x20);                   // bit 5 (32): no weights-stationary kernel (the 64-channel layers stay on igemm3)
+  g_igemm4p = !(version & 0x40);                  // bit 6 (64): no phase-per-wave variant of it (128 -> 64 transposed gathers)
   g_use_igemm2 = g_conv_kernel != 1;
   g_dbg = version >> 8;
 }
