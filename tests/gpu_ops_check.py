@@ -121,6 +121,11 @@ CASES = [
     # weights-stationary persistent kernel (igemm4: 64 -> 64 3x3, whole 8 x 32 tiles)
     (2, 32, 64, 64, 64, 3, 1, 1),     # fewer tiles than blocks
     (6, 96, 128, 64, 64, 3, 1, 1),    # 288 tiles on 256 blocks: a second tile for some, XCD-ordered hand-out
+    # its variants: output channels split over the waves (igemm4c: 128 -> 128 3x3, 4 x 32 tiles), a phase per wave
+    # (igemm4p: the input gradient of a 64 -> 128 4x4 stride-2 conv = 128 -> 64 transposed gather, 2 x 32 tiles)
+    (3, 36, 96, 128, 128, 3, 1, 1),   # 81 tiles
+    (5, 72, 128, 128, 128, 3, 1, 1),  # 360 tiles on 256 blocks
+    (5, 72, 128, 64, 128, 4, 2, 1),   # dgrad: 5 x 18 x 2 = 180 tiles of 2 x 32 input pixels
 ]
 
 if __name__ == "__main__":

@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     // K loop, 36 steps of 4 MFMAs, fully unrolled; the two A fragments of step t+PD are requested before the MFMAs of
     // step t (one wave per SIMD: nobody else hides the LDS latency)
     constexpr int KSTEPS = CCH * NTAPS * 2;
-    static_assert(2 * HRN <= KSTEPS - 8, "halo rounds on the even steps, done well before the loop ends");
+    static_assert(2 * HRN <= KSTEPS - 8 && ST0 + 18 <= KSTEPS, "halo rounds on the even steps, done well before the loop ends; 8 stores fit");
     auto a_addr = [&](int t) {
       const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
       const int r = tap / S, s = tap % S;
@@ -1449,46 +1449,49 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
       const int va = a_addr(t);
       fa[t][0] = *(const u32x4*)(hb + va); fa[t][1] = *(const u32x4*)(hb + va + HSB);
     }
-#pragma unroll
+    // The first AFRAGS weight fragments live in accumulation registers, the rest (and the accumulators) in ordinary
+    // ones: 288 + 64 registers do not fit either file alone.  With the builtin the compiler kept the weights in
+    // accumulation registers but copied every fragment into the same four ordinary ones in front of its MFMAs (it never
+    // names an accumulation register as a multiplicand), and those copies had to wait for the previous MFMA to read them.
+    auto mfma = [&](int t, int i, int j) {
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
+      const bool in_a = ((tap * CCH + cc) * 2 + kk) * 2 + j < AFRAGS;
+      static_assert(AFRAGS >= 2, "the first step's fragments are in accumulation registers");
+      if (t == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[i][j]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk][j]));
+      else if (in_a) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk][j]));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk][j]));
+    };
+    // One K step = 4 MFMAs (32 cycles each; an MFMA holds the wave's issue for 8 of them).  The step's other work is
+    // dealt out over the four gaps so that no gap's issue cost runs far past the MFMA behind it: the two A-fragment
+    // prefetches in the first two, a halo round or a staging read in the third, a deferred store in the fourth.
+#pragma clang loop unroll(full)
     for (int t = 0; t < KSTEPS; ++t) {
-      if (t + PD < KSTEPS) {
-        const int va = a_addr(t + PD);
-        fa[(t + PD) % (PD + 1)][0] = *(const u32x4*)(hb + va); fa[(t + PD) % (PD + 1)][1] = *(const u32x4*)(hb + va + HSB);
-      }
+      const int vp = t + PD < KSTEPS ? a_addr(t + PD) : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + PD < KSTEPS) fa[(t + PD) % (PD + 1)][0] = *(const u32x4*)(hb + vp);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + PD < KSTEPS) fa[(t + PD) % (PD + 1)][1] = *(const u32x4*)(hb + vp + HSB);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 0, 1);
+      __builtin_amdgcn_sched_barrier(0);
       if (t % 2 == 0 && t / 2 < HRN) { if (has_next) halo_round(t / 2, buf ^ 1); }
-      if (ACC && t == 0) {
+      if (ACC && t == 1) {
         if (has_prev) {
 #pragma unroll
           for (int sidx = 0; sidx < 8; ++sidx) oreg[sidx] = *(const u32x4*)store_ptr(sidx);
         }
       }
-      if (t >= ST0 && (t - ST0) % 2 == 0 && (t - ST0) / 2 < 8) { if (has_prev) sreg = stage_piece((t - ST0) / 2); }
-      if (t >= ST0 && (t - ST0) % 2 == 1 && (t - ST0) / 2 < 8) { if (has_prev) store_piece((t - ST0) / 2, sreg, oreg[(t - ST0) / 2]); }
+      if (t >= ST0 && (t - ST0) % 2 == 1 && (t - ST0) / 2 < 8) { if (has_prev) sreg = stage_piece((t - ST0) / 2); }
       __builtin_amdgcn_sched_barrier(0);
-      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
-      if (VG_DBG4(16) && t >= 2) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        // the first AFRAGS weight fragments live in accumulation registers, the rest (and the accumulators) in
-        // ordinary ones: 288 + 64 registers do not fit either file alone.  With the builtin the compiler kept the
-        // weights in accumulation registers but copied every fragment into the same four ordinary ones in front of its
-        // MFMAs (it never names an accumulation register as a multiplicand), and those copies had to wait for the
-        // previous MFMA to read them: 62 % of the MFMA rate.
-        const bool in_a = ((tap * CCH + cc) * 2 + kk) * 2 + j < AFRAGS;
-        if (t == 0) {
-          static_assert(AFRAGS >= 2, "the first step's fragments are in accumulation registers");
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[0][j]) : "v"(fa[0][0]), "a"(fb[tap][cc][kk][j]));
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[1][j]) : "v"(fa[0][1]), "a"(fb[tap][cc][kk][j]));
-        } else if (in_a) {
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][j]) : "v"(fa[t % (PD + 1)][0]), "a"(fb[tap][cc][kk][j]));
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][j]) : "v"(fa[t % (PD + 1)][1]), "a"(fb[tap][cc][kk][j]));
-        } else {
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[0][j]) : "v"(fa[t % (PD + 1)][0]), "v"(fb[tap][cc][kk][j]));
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[1][j]) : "v"(fa[t % (PD + 1)][1]), "v"(fb[tap][cc][kk][j]));
-        }
-      }
+      mfma(t, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
+      if (t >= ST0 + 2 && (t - ST0) % 2 == 0 && (t - ST0 - 2) / 2 < 8) { if (has_prev) store_piece((t - ST0 - 2) / 2, sreg, oreg[(t - ST0 - 2) / 2]); }
     }
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
     __builtin_amdgcn_sched_barrier(0);
     VG_T(1);
@@ -1531,7 +1534,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     VG_T(2);
     {
       // stores issued after the last halo round (K step 2*HRN-2): they may stay in flight
-      constexpr int LATE = [] { int n = 0; for (int s_ = 0; s_ < 8; ++s_) n += ST0 + 1 + 2 * s_ > 2 * HRN - 2; return n; }();
+      constexpr int LATE = [] { int n = 0; for (int s_ = 0; s_ < 8; ++s_) n += ST0 + 2 + 2 * s_ >= 2 * HRN - 2; return n; }();
       if (ACC && has_prev && VG_ABLATE_LEVEL < 2) wait_vmcnt<LATE>(); else wait_vmcnt<0>();
     }
     VG_T(3);
@@ -1573,7 +1576,266 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   }
 }
 
-static bool g_igemm4 = true, g_igemm4p = true;
+// =============================================================================================
+// igemm4c: the weights-stationary kernel for 128 output channels (the 128 -> 128 3x3 convolutions and their input
+// gradients).  9 x 128 x 128 weights do not fit one wave's registers, so the four waves of a block split the OUTPUT
+// CHANNELS: wave w keeps the 72 fragments of channels 32w .. 32w+31 (all taps, all 128 input channels) and computes
+// them for every pixel of a 4 x 32 tile (4 accumulators).  All four waves read the same A fragments: one LDS read
+// per MFMA per wave, half of what the LDS array delivers.  Halo prefetch, deferred output stores, statistics and tile
+// hand-out as in igemm4; the halo piece table is packed into 4 bytes per entry to fit two 54 KB halo images.
+// =============================================================================================
+#ifndef VG_IGEMM4C_PD
+#define VG_IGEMM4C_PD 3
+#endif
+template <int CCH>
+struct Igemm4cCfg {
+  static constexpr int R = 3, S = 3, NT = 256, TW = 32, TH = 4, BN = 128, NTAPS = 9;
+  static constexpr int HS = 35, HSB = HS * 64, HH = TH + R - 1, CHB = HH * HSB;
+  static constexpr int NPIECE = CCH * HH * HS * 4;
+  static constexpr int HRN = (NPIECE + NT - 1) / NT;
+  static constexpr int HBYTES = NPIECE * 16;                    // exact: lanes past the image's end do not write
+  static constexpr int WTILE = TH * 32 * 32 * 2;                // per-wave output staging: 4 rows x 32 px x 32 ch bf16
+  static constexpr int OFF_STAGE = 2 * HBYTES;
+  static constexpr int OFF_TAB = OFF_STAGE + 4 * WTILE;         // [HRN][NT] packed halo piece table
+  static constexpr int LDS = OFF_TAB + HRN * NT * 4;
+  static constexpr int KSTEPS = CCH * NTAPS * 2;
+  static constexpr bool FITS = LDS <= 160 * 1024 && NTAPS * CCH * 2 * 4 <= 320;
+};
+
+template <int CCH, bool LR, bool ST, bool ACC>
+__global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
+  typedef Igemm4cCfg<CCH> Cfg;
+  typedef bf16_t T;
+  constexpr int R = 3, S = 3, NT = Cfg::NT, TW = Cfg::TW, TH = Cfg::TH, BN = Cfg::BN, NTAPS = Cfg::NTAPS;
+  constexpr int HS = Cfg::HS, HSB = Cfg::HSB, HH = Cfg::HH, CHB = Cfg::CHB, HRN = Cfg::HRN, HBYTES = Cfg::HBYTES;
+  constexpr int PIECE = 8, WTILE = Cfg::WTILE, KSTEPS = Cfg::KSTEPS;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = block of 32 output channels
+  const int h = lane >> 5, l32 = lane & 31;
+  const int tpi = p.tilesX * p.tilesY;
+  const int dymin = p.dymin_i[0], dxmin = p.dxmin_i[0];
+  const bool flip = p.flip != 0;
+  const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
+  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
+  const unsigned smem0 = lds_addr_of(smem);
+
+  // ---- this wave's weights: fb[tap][cc][kk]: channel 32*wave + l32, k = cc*32 + kk*16 + 8h..
+  u32x4 fb[NTAPS][CCH][2];
+  {
+    const size_t ktot = (size_t)NTAPS * p.C;
+    const T* wg = (const T*)p.w + ((size_t)32 * wave + l32) * ktot;
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap)
+#pragma unroll
+      for (int cc = 0; cc < CCH; ++cc)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          fb[tap][cc][kk] = *(const u32x4*)(wg + (size_t)tap * p.C + cc * 32 + (2 * kk + h) * PIECE);
+  }
+  // ---- halo piece table: hy | hx << 4 | cc << 10 | source slot << 13 | inside the image columns << 15 | exists << 16
+  unsigned* ptab = (unsigned*)(smem + Cfg::OFF_TAB) + tid;
+#pragma unroll
+  for (int rd = 0; rd < HRN; ++rd) {
+    const int q = rd * NT + tid;
+    const int cc = q / (HH * HS * 4), rem = q - cc * (HH * HS * 4);
+    const int pix = rem >> 2, ps = rem & 3;
+    const int hy = pix / HS, hx = pix - hy * HS;
+    ptab[rd * NT] = (unsigned)hy | (unsigned)hx << 4 | (unsigned)cc << 10 | (unsigned)((ps ^ (hx >> 2)) & 3) << 13 |
+                    (unsigned)(hx < TW + S - 1) << 15 | (unsigned)(q < Cfg::NPIECE) << 16;
+  }
+  const bool xcd_order = gridDim.x == 256;
+  auto tile_of = [&](int k) { return xcd_order ? ((k * 8 + (int)(blockIdx.x & 7)) * 32 + (int)(blockIdx.x >> 3)) : k * (int)gridDim.x + (int)blockIdx.x; };
+  auto tile_origin = [&](int tile, int& img, int& ty0, int& tx0) {
+    img = tile / tpi;
+    const int trem = tile - img * tpi;
+    const int ty = trem / p.tilesX;
+    ty0 = ty * TH; tx0 = (trem - ty * p.tilesX) * TW;
+  };
+  int ct[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int hx = l32 + (flip ? S - 1 - s : s);
+    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4);
+  }
+  const float bv = p.bias != nullptr ? p.bias[32 * wave + l32] : 0.f;
+  double st1 = 0.0, st2 = 0.0;
+  T* __restrict__ yg = (T*)p.y;
+  T* wt = (T*)(smem + Cfg::OFF_STAGE + wave * WTILE);      // [4 rows][32 px][32 ch]
+
+  unsigned e = ptab[0];
+  const unsigned char* hbase = nullptr;
+  int hiy0 = 0, hix0 = 0;
+  auto halo_begin = [&](int tile) {
+    int img, ty0, tx0;
+    tile_origin(tile, img, ty0, tx0);
+    hiy0 = ty0 + dymin; hix0 = tx0 + dxmin;
+    hbase = xg + ((long)((long)img * p.H + hiy0) * p.W + hix0) * p.Cs * 2;
+  };
+  const int wcs2 = p.W * p.Cs * 2, cs2 = p.Cs * 2;
+  auto halo_round = [&](int rd, int buf) {
+    const int hy = e & 15, hx = (e >> 4) & 63;
+    const bool in = (e >> 15 & 1) && (unsigned)(hiy0 + hy) < (unsigned)p.H && (unsigned)(hix0 + hx) < (unsigned)p.W;
+    const int off = hy * wcs2 + hx * cs2 + (int)((e >> 10 & 7) * 64 + (e >> 13 & 3) * 16);
+    if (e >> 16 & 1) lds_dma16(in ? hbase + off : zsrc, smem0 + buf * HBYTES + (rd * NT + wave * 64) * 16);
+    e = ptab[(rd + 1 == HRN ? 0 : rd + 1) * NT];
+  };
+  // deferred stores of the previous tile: piece sidx = row sidx / 2, pixels 16 * (sidx & 1) + lane / 4, 16 bytes lane % 4
+  auto stage_piece = [&](int sidx) {
+    return *(const u32x4*)(wt + (sidx >> 1) * 1024 + ((lane + 64 * (sidx & 1)) >> 2) * 32 + (lane & 3) * PIECE);
+  };
+  T* pdst = nullptr;
+  auto store_ptr = [&](int sidx) { return pdst + (size_t)(sidx >> 1) * p.OW * BN + (sidx & 1) * 16 * BN; };
+  auto store_piece = [&](int sidx, u32x4 v, u32x4 old) {
+    if (ACC) {
+      Piece<T> o, q;
+      o.v = __builtin_bit_cast(bf16x8, v); q.v = __builtin_bit_cast(bf16x8, old);
+#pragma unroll
+      for (int e_ = 0; e_ < PIECE; ++e_) o.set(e_, o.get(e_) + q.get(e_));
+      v = __builtin_bit_cast(u32x4, o.v);
+    }
+    *(u32x4*)store_ptr(sidx) = v;
+  };
+  constexpr int NST = 2 * TH;                  // stores per wave per tile
+  constexpr int ST0 = ACC ? 2 * HRN + 2 : 0;   // ACC: old values requested at K step 0, stores behind the halo rounds
+  static_assert(2 * HRN <= KSTEPS - 8 && ST0 + 2 * NST + 2 <= KSTEPS, "halo rounds and stores fit the K loop");
+
+  int tile = tile_of(0);
+  if (tile < p.mtiles) {
+    halo_begin(tile);
+#pragma unroll
+    for (int rd = 0; rd < HRN; ++rd) halo_round(rd, 0);
+  }
+  wait_vmcnt<0>();
+  bool has_prev = false;
+  int buf = 0;
+  for (int k = 0; tile < p.mtiles; ++k, buf ^= 1) {
+    const int next = tile_of(k + 1);
+    const bool has_next = next < p.mtiles;
+    int img, ty0, tx0;
+    tile_origin(tile, img, ty0, tx0);
+    if (has_next) halo_begin(next);
+    __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
+    f32x16 acc[TH];
+    const unsigned char* hb = smem + buf * HBYTES;
+    auto a_addr = [&](int t) {
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
+      const int r = tap / S, s = tap % S;
+      const int va0 = ct[s] + cc * CHB + (flip ? R - 1 - r : r) * HSB;
+      return kk ? va0 ^ 32 : va0;
+    };
+    constexpr int PD = ACC ? 2 : VG_IGEMM4C_PD, AFRAGS = 64;      // prefetch distance of the A fragments in K steps
+    u32x4 fa[PD + 1][TH];
+    u32x4 sreg = u32x4{0, 0, 0, 0};
+    u32x4 oreg[NST];
+#pragma unroll
+    for (int sidx = 0; sidx < NST; ++sidx) oreg[sidx] = u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < PD; ++t) {
+      const int va = a_addr(t);
+#pragma unroll
+      for (int i = 0; i < TH; ++i) fa[t][i] = *(const u32x4*)(hb + va + i * HSB);
+    }
+    // One K step = 4 MFMAs (32 cycles each; an MFMA holds the wave's issue for 8 of them).  The step's other work is dealt
+    // out over the four gaps so that no gap's issue cost runs far past the MFMA behind it: A-fragment prefetch in the
+    // first two, a halo round or a staging read in the third, a deferred store in the fourth.
+    auto mfma = [&](int t, int i) {
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
+      const bool in_a = (tap * CCH + cc) * 2 + kk < AFRAGS;        // 64 fragments in accumulation registers, 8 in ordinary ones
+      if (t == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk]));
+      else if (in_a) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk]));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk]));
+    };
+#pragma clang loop unroll(full)
+    for (int t = 0; t < KSTEPS; ++t) {
+      const int vp = t + PD < KSTEPS ? a_addr(t + PD) : 0;
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + PD < KSTEPS) {
+        fa[(t + PD) % (PD + 1)][0] = *(const u32x4*)(hb + vp);
+        fa[(t + PD) % (PD + 1)][1] = *(const u32x4*)(hb + vp + HSB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + PD < KSTEPS) {
+        fa[(t + PD) % (PD + 1)][2] = *(const u32x4*)(hb + vp + 2 * HSB);
+        fa[(t + PD) % (PD + 1)][3] = *(const u32x4*)(hb + vp + 3 * HSB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t % 2 == 0 && t / 2 < HRN) { if (has_next) halo_round(t / 2, buf ^ 1); }
+      if (ACC && t == 1) {
+        if (has_prev) {
+#pragma unroll
+          for (int sidx = 0; sidx < NST; ++sidx) oreg[sidx] = *(const u32x4*)store_ptr(sidx);
+        }
+      }
+      if (t >= ST0 && (t - ST0) % 2 == 1 && (t - ST0) / 2 < NST) { if (has_prev) sreg = stage_piece((t - ST0) / 2); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t >= ST0 + 2 && (t - ST0) % 2 == 0 && (t - ST0 - 2) / 2 < NST) { if (has_prev) store_piece((t - ST0 - 2) / 2, sreg, oreg[(t - ST0 - 2) / 2]); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue: statistics of the bf16-rounded pre-activation, activation; the four rows into the staging tile
+    {
+      f32x2 a1 = f32x2{0.f, 0.f}, a2 = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TH; ++i) {
+        T* wl = wt + i * 1024 + 4 * h * 32 + l32;
+#pragma unroll
+        for (int r2 = 0; r2 < 8; ++r2) {
+          const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2);
+          f32x2 v = f32x2{acc[i][r], acc[i][r + 1]} + bv;
+          bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+          if (ST || LR) v = __builtin_convertvector(q, f32x2);
+          if (ST) { a1 += v; a2 += v * v; }
+          if (LR) {
+            const f32x2 w = v * VG_LRELU_SLOPE;
+            f32x2 m;
+            asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
+            q = __builtin_convertvector(m, bf16x2_t);
+          }
+          wl[row * 32] = q[0];
+          wl[(row + 1) * 32] = q[1];
+        }
+      }
+      if (ST) { st1 += (double)(a1[0] + a1[1]); st2 += (double)(a2[0] + a2[1]); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    pdst = yg + ((((size_t)img * p.OH + ty0) * p.OW + tx0 + (lane >> 2)) * BN + 32 * wave + (lane & 3) * PIECE);
+    has_prev = true;
+    if (ACC && k > 0) wait_vmcnt<NST>(); else wait_vmcnt<0>();     // ACC: this tile's stores all sit behind the last halo round
+    tile = next;
+  }
+  if (has_prev) {
+#pragma unroll
+    for (int sidx = 0; sidx < NST; ++sidx) {
+      u32x4 old = u32x4{0, 0, 0, 0};
+      if (ACC) old = *(const u32x4*)store_ptr(sidx);
+      store_piece(sidx, stage_piece(sidx), old);
+    }
+  }
+  if (ST) {
+    const double s1 = st1 + __shfl_xor(st1, 32, 64), s2 = st2 + __shfl_xor(st2, 32, 64);
+    if (h == 0) {
+      vg_stats_add(p.stats, p.Npad, 0, 32 * wave + l32, blockIdx.x, s1, p.det);
+      vg_stats_add(p.stats, p.Npad, 1, 32 * wave + l32, blockIdx.x, s2, p.det);
+    }
+  }
+}
+
+static bool g_igemm4 = true, g_igemm4p = true, g_igemm4c = true;
 template <int R, int S, int CCH, bool LR, bool ST, bool ACC, bool PH>
 static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
   typedef Igemm4Cfg<R, S, CCH, PH> Cfg;
@@ -1630,9 +1892,60 @@ static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
   *handled = true;
   return VG_OK;
 }
+template <int CCH, bool LR, bool ST, bool ACC>
+static int launch_igemm4c(const IgemmParams& p0, hipStream_t st, bool* handled) {
+  typedef Igemm4cCfg<CCH> Cfg;
+  static_assert(Cfg::FITS, "igemm4c configuration does not fit");
+  *handled = false;
+  IgemmParams p = p0;
+  int ymin = 127, xmin = 127;
+  for (int t = 0; t < 9; ++t) {
+    ymin = p.dy[0][t] < ymin ? p.dy[0][t] : ymin;
+    xmin = p.dx[0][t] < xmin ? p.dx[0][t] : xmin;
+  }
+  p.dymin[0] = (signed char)ymin; p.dxmin[0] = (signed char)xmin;
+  bool asc = true, desc = true;
+  for (int t = 0; t < 9; ++t) {
+    const int yo = p.dy[0][t] - ymin, xo = p.dx[0][t] - xmin;
+    asc = asc && yo == t / 3 && xo == t % 3;
+    desc = desc && yo == 2 - t / 3 && xo == 2 - t % 3;
+  }
+  if (!asc && !desc) return VG_OK;
+  p.flip = asc ? 0 : 1;
+  if ((size_t)p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31)) return VG_OK;
+  p.tilesX = p.OWl / Cfg::TW;
+  p.tilesY = p.OHl / Cfg::TH;
+  p.mtiles = p.N * p.tilesX * p.tilesY;
+  p.ntiles = 1;
+  auto kern = igemm4c_kernel<CCH, LR, ST, ACC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
+    attr_set = true;
+  }
+  pack_taps(p);
+  const int blocks = p.mtiles < 256 ? p.mtiles : 256;
+  snprintf(g_last_kernel, sizeof g_last_kernel, "igemm4c<bf16,3x3,%d>", CCH);
+  hipLaunchKernelGGL(kern, dim3(blocks, 1), dim3(Cfg::NT), Cfg::LDS, st, p);
+  VG_LAUNCH_CHECK();
+  *handled = true;
+  return VG_OK;
+}
 template <typename T> static int dispatch_igemm4(const IgemmParams& p, hipStream_t st, bool* handled) {
   *handled = false;
   if constexpr (sizeof(T) == 2) {
+    // 128 -> 128 3x3: output channels split over the waves
+    if (g_igemm4c && !g_conv_kernel_is_old() && p.ksplit <= 1 && p.in_s == 1 && p.nphases == 1 && p.out_s == 1 && p.ntaps == 9 &&
+        p.C == 128 && p.Npad == 128 && p.Nout == 128 && p.Ks == 128 && p.OWl % 32 == 0 && p.OHl % 4 == 0 &&
+        (p.act == VG_ACT_NONE || p.act == VG_ACT_LRELU)) {
+      const bool lr = p.act == VG_ACT_LRELU, st_ = p.stats != nullptr;
+      if (p.accumulate) {
+        if (lr || st_) return VG_OK;
+        return launch_igemm4c<4, false, false, true>(p, st, handled);
+      }
+      if (lr) return st_ ? launch_igemm4c<4, true, true, false>(p, st, handled) : launch_igemm4c<4, true, false, false>(p, st, handled);
+      return st_ ? launch_igemm4c<4, false, true, false>(p, st, handled) : launch_igemm4c<4, false, false, false>(p, st, handled);
+    }
     // whole tiles, 64 real output channels at stride 64: everything else stays on igemm3
     if (!g_igemm4 || g_conv_kernel_is_old() || p.ksplit > 1 || p.in_s != 1 || p.Npad != 64 || p.Nout != 64 || p.Ks != 64 ||
         p.OWl % 32 != 0 || (p.act != VG_ACT_NONE && p.act != VG_ACT_LRELU))
@@ -1687,6 +2000,7 @@ extern "C" void vg_set_conv_kernel(int version) {
   g_conv_kernel = version & 0x0f;                 // bit 4 (16): stride-2 forward stays on the im2col-row kernel
   g_igemm3_s2 = !(version & 0x10);
   g_igemm4 = !(version & 0x20);                   // bit 5 (32): no weights-stationary kernel (the 64-channel layers stay on igemm3)
+  g_igemm4c = !(version & 0x80);                  // bit 7 (128): no channel-split variant (128 -> 128 3x3 stays on igemm3)
   g_igemm4p = !(version & 0x40);                  // bit 6 (64): no phase-per-wave variant of it (128 -> 64 transposed gathers)
   g_use_igemm2 = g_conv_kernel != 1;
   g_dbg = version >> 8;
