@@ -273,7 +273,7 @@ static int attn_check(int b, int hw, int d, int c) {
 #define ATTN_DISPATCH(KERN, NWV, LDS, GRIDX, ...)                                                            \
   do {                                                                                                        \
     auto kern_ = KERN;                                                                                        \
-    VG_HIP(hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    VG_HIP(vg_lds_attr((const void*)kern_, 160 * 1024)); \
     hipLaunchKernelGGL(kern_, dim3(GRIDX, b), dim3(NWV * 64), LDS, st, __VA_ARGS__);                          \
   } while (0)
 

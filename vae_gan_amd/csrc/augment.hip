@@ -245,7 +245,7 @@ int vg_augment_batch(const vg_aug_item* items, int n, int out_h, int out_w, void
   VG_HIP(hipMemcpyAsync(ws, table, (size_t)n * ITEM * sizeof(int64_t), hipMemcpyHostToDevice, s));
   VG_HIP(hipEventRecord(st.ev, s));
   st.pending = true;
-  VG_HIP(hipFuncSetAttribute((const void*)aug_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  VG_HIP(vg_lds_attr((const void*)aug_h_kernel, 150 * 1024));
   const int rpb_h = 16;
   dim3 gh(n, (p.max_rows + rpb_h - 1) / rpb_h);
   aug_h_kernel<<<gh, 256, lds_h, s>>>((const int64_t*)ws, OH, S, (uint8_t*)ws, rpb_h, p.kmax, row_dwords);

@@ -393,7 +393,7 @@ int vg_ac_decode(const uint8_t* data, const int* nbytes, int n_streams, int64_t 
   const size_t tbl = sizeof(double) * ((size_t)k + 1);
   hipStream_t s = (hipStream_t)stream;
   if (tbl <= 96 * 1024) {      // table in LDS (K <= 12287); two waves' worth of blocks still share a CU at K = 8192
-    VG_HIP(hipFuncSetAttribute((const void*)ac_decode_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    VG_HIP(vg_lds_attr((const void*)ac_decode_kernel<true>, 96 * 1024));
     ac_decode_kernel<true><<<n_streams, 64, tbl, s>>>(data, nbytes, cap_per_stream, symbols_per_stream, cum, k, indices, status);
   } else {
     ac_decode_kernel<false><<<n_streams, 64, 0, s>>>(data, nbytes, cap_per_stream, symbols_per_stream, cum, k, indices, status);

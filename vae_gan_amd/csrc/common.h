@@ -48,6 +48,10 @@ void vg_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): thread-safe, and a second GPU in the
+// same process gets its own call (a function-local `static bool` is neither).  Defined in pack.hip.
+hipError_t vg_lds_attr(const void* kernel, int bytes);
+
 static inline int vg_elt_size(int dtype) { return dtype == VG_BF16 ? 2 : 4; }
 static inline int64_t vg_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -351,11 +351,7 @@ static int launch_igemm(const IgemmParams& p0, hipStream_t st) {
   p.mtiles = (int)vg_ceil_div(p.M, BM);
   p.ntiles = p.Npad / BN;
   auto kern = igemm_kernel<T, MI, NI, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)kern, (int)lds));
   dim3 grid(p.mtiles * p.ntiles, p.nphases, p.ksplit);
   pack_taps(p);
   snprintf(g_last_kernel, sizeof g_last_kernel, "igemm<%s,%d,%d,%d,%d>%s", tname<T>(), MI, NI, WM, WN, p.ksplit > 1 ? "+splitk" : "");
@@ -637,11 +633,7 @@ static int launch_igemm2(const IgemmParams& p0, hipStream_t st, bool* handled) {
   p.mtiles = p.N * p.tilesX * p.tilesY;
   p.ntiles = p.Npad / BN;
   auto kern = igemm2_kernel<T, MI, NI, WM, WN, TH>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));
   pack_taps(p);
   snprintf(g_last_kernel, sizeof g_last_kernel, "igemm2<%s,%d,%d,%d,%d,%d>", tname<T>(), MI, NI, WM, WN, TH);
   hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.nphases), dim3(NT), lds, st, p);
@@ -1168,11 +1160,7 @@ static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
     p.mtiles = p.N * p.tilesX * p.tilesY;
     p.ntiles = p.Npad / Cfg::BN;
     auto kern = igemm3_kernel<T, MI, NI, WM, WN, R, S>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+      VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));
     pack_taps(p);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm3<%s,%d,%d,%d,%d,%dx%d>", tname<T>(), MI, NI, WM, WN, R, S);
     hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.nphases), dim3(Cfg::NT), Cfg::LDS, st, p);
@@ -1205,11 +1193,7 @@ static int launch_igemm3s2(const IgemmParams& p0, hipStream_t st, bool* handled)
     p.mtiles = p.N * p.tilesX * p.tilesY;
     p.ntiles = p.Npad / Cfg::BN;
     auto kern = igemm3s2_kernel<T, MI, NI, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+      VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));
     pack_taps(p);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm3s2<%s,%d,%d,%d,%d>", tname<T>(), MI, NI, WM, WN);
     hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, 1), dim3(Cfg::NT), Cfg::LDS, st, p);
@@ -1879,11 +1863,7 @@ static int launch_igemm4(const IgemmParams& p0, hipStream_t st, bool* handled) {
   p.splitws = (float*)g_stamp_buf;
 #endif
   auto kern = igemm4_kernel<R, S, CCH, LR, ST, ACC, PH>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)kern, Cfg::LDS));
   pack_taps(p);
   const int blocks = p.mtiles < 256 ? p.mtiles : 256;    // one persistent block per CU
   snprintf(g_last_kernel, sizeof g_last_kernel, PH ? "igemm4p<bf16,%dx%d,%d>" : "igemm4<bf16,%dx%d,%d>", R, S, CCH);
@@ -1918,11 +1898,7 @@ static int launch_igemm4c(const IgemmParams& p0, hipStream_t st, bool* handled) 
   p.mtiles = p.N * p.tilesX * p.tilesY;
   p.ntiles = 1;
   auto kern = igemm4c_kernel<CCH, LR, ST, ACC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)kern, Cfg::LDS));
   pack_taps(p);
   const int blocks = p.mtiles < 256 ? p.mtiles : 256;
   snprintf(g_last_kernel, sizeof g_last_kernel, "igemm4c<bf16,3x3,%d>", CCH);
@@ -2479,11 +2455,7 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t st) {
   p.chunks_per_split = (int)vg_ceil_div(p.nchunks, splits);
   splits = (int)vg_ceil_div(p.nchunks, p.chunks_per_split);
   auto kern = wgrad_kernel<T, OI, CI, WO, WC, WK>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)kern, (int)lds));
   hipLaunchKernelGGL(kern, dim3(base_blocks, splits), dim3(256), lds, st, p);
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -2718,11 +2690,7 @@ static int launch_wgrad3(const WgradParams& p0, hipStream_t st) {
   const int pairs = p.otiles * p.ctiles;
   const int G = wg3_groups(pairs, p.N, p.OH, p.OW, Cfg::TH, Cfg::TW);
   auto kern = wgrad3_kernel<NOB, NCB, KS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)kern, Cfg::LDS));
   hipLaunchKernelGGL(kern, dim3(pairs * G), dim3(512), Cfg::LDS, st, p);
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -2911,11 +2879,7 @@ static int launch_wgrad3s2(const WgradParams& p0, hipStream_t st) {
   const int pairs = p.otiles * p.ctiles;
   const int G = wg3_groups(pairs, p.N, p.OH, p.OW, Cfg::TH, Cfg::TW);
   auto kern = wgrad3s2_kernel<NOB, NCB, KS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)kern, Cfg::LDS));
   hipLaunchKernelGGL(kern, dim3(pairs * G), dim3(512), Cfg::LDS, st, p);
   VG_LAUNCH_CHECK();
   return VG_OK;

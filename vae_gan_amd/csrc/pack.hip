@@ -2,6 +2,9 @@
 #include <stdarg.h>
 
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 #include <mutex>
 
 // ---------------------------------------------------------------------------------------------
@@ -150,12 +153,8 @@ extern "C" int vg_conv_pack_batch(const void* items_dev, int n_items, int dtype,
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "pack_batch: bad dtype %d", dtype);
   dim3 grid(256, n_items);                               // a block per 32 x 32 tile: 512 x 512 channels = 256 tiles
   const size_t lds = (size_t)32 * (32 * 17 + 1) * sizeof(float);      // RS <= 16
-  static bool attr_set = false;
-  if (!attr_set) {
-    VG_HIP(hipFuncSetAttribute((const void*)pack_batch_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    VG_HIP(hipFuncSetAttribute((const void*)pack_batch_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+    VG_HIP(vg_lds_attr((const void*)pack_batch_kernel<bf16_t>, (int)lds));
+    VG_HIP(vg_lds_attr((const void*)pack_batch_kernel<float>, (int)lds));
   if (dtype == VG_BF16) hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const PackParams*)items_dev);
   else hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const PackParams*)items_dev);
   VG_LAUNCH_CHECK();
@@ -264,6 +263,20 @@ extern "C" int vg_nhwc_to_nchw(const void* src, float* dst, int n, int c, int h,
 // across blocks: statistics go through the fixed-point accumulators of common.h, kernels that split a reduction
 // over blocks with f32 atomics run unsplit or on an ordered variant.
 // ---------------------------------------------------------------------------------------------
+hipError_t vg_lds_attr(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;      // (kernel, device) -> bytes granted
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({kernel, dev});
+  if (it != done.end() && it->second >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[{kernel, dev}] = bytes;
+  return e;
+}
+
 static int g_det_mode = 0;
 int vg_det_mode(void) { return g_det_mode; }
 extern "C" void vg_set_deterministic(int on) { g_det_mode = on ? 1 : 0; }

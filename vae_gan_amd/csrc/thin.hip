@@ -440,7 +440,7 @@ template <int R, int ST> static constexpr int thin_wgrad_lds() {
   return 2 * 64 * 264 * 2 + ((8 - 1) * ST + R) * ((32 - 1) * ST + R + (((32 - 1) * ST + R) & 1) + 2) * 8;
 }
 template <typename K> static int thin_lds_attr(K kern, int bytes) {
-  VG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  VG_HIP(vg_lds_attr((const void*)kern, bytes));
   return VG_OK;
 }
 static void thin_tiles(ThinParams& p, int gh, int gw, int th, int tw) {

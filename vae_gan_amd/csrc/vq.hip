@@ -184,8 +184,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign2_kernel(const float* __restr
 template <int D>
 static int launch_vq_assign2(const float* z, const float* cb, float* e2, int64_t rows, int k, int64_t* idx, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * 32 * 2 * (D / 2 + 4) + 64) * sizeof(float);
-  static bool set = false;
-  if (!set) { VG_HIP(hipFuncSetAttribute((const void*)vq_assign2_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+  VG_HIP(vg_lds_attr((const void*)vq_assign2_kernel<D>, (int)lds));
   hipLaunchKernelGGL(vq_code_norms_kernel, dim3((unsigned)vg_ceil_div(k, 256)), dim3(256), 0, st, cb, k, D, e2);
   VG_LAUNCH_CHECK();
   hipLaunchKernelGGL(vq_assign2_kernel<D>, dim3((unsigned)vg_ceil_div(rows, 128)), dim3(256), lds, st, z, cb, (const float*)e2, rows, k, idx);
@@ -207,12 +206,10 @@ extern "C" int vg_vq_assign(const float* z, const float* codebook, int64_t rows,
   const size_t lds = ((size_t)(nw * 32 + 64) * (d + 1) + 64) * sizeof(float);
   const unsigned blocks = (unsigned)vg_ceil_div(rows, nw * 32);
   if (nw == 4) {
-    static bool set4 = false;
-    if (!set4) { VG_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set4 = true; }
+    VG_HIP(vg_lds_attr((const void*)vq_assign_kernel<4>, 160 * 1024));
     hipLaunchKernelGGL(vq_assign_kernel<4>, dim3(blocks), dim3(256), lds, st, z, codebook, rows, k, d, idx);
   } else {
-    static bool set2 = false;
-    if (!set2) { VG_HIP(hipFuncSetAttribute((const void*)vq_assign_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set2 = true; }
+    VG_HIP(vg_lds_attr((const void*)vq_assign_kernel<2>, 160 * 1024));
     hipLaunchKernelGGL(vq_assign_kernel<2>, dim3(blocks), dim3(128), lds, st, z, codebook, rows, k, d, idx);
   }
   VG_LAUNCH_CHECK();
@@ -356,7 +353,7 @@ extern "C" int vg_vq_gather(const float* z, const float* codebook, const int64_t
   const size_t lds = sizeof(float) * ((size_t)k * d + k);
   const int det = vg_det_mode();
   if (esum != nullptr && lds <= 144 * 1024 && rows >= 8192 && !det) {
-    VG_HIP(hipFuncSetAttribute((const void*)vq_gather_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    VG_HIP(vg_lds_attr((const void*)vq_gather_lds_kernel, 144 * 1024));
     const int rpb1 = 1024 / (d / 4);
     int64_t nb = vg_ceil_div(rows, (int64_t)rpb1 * 16);        // >= 16 rows per thread before a block pays its flush
     if (nb > 128) nb = 128;
