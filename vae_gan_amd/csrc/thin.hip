@@ -14,6 +14,7 @@
 // All three read the master OIHW f32 weights themselves (a few thousand values): no packed weight images.
 // Every kernel is bound by the one pass over the 64-channel tensor it touches (HBM).
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
@@ -128,10 +129,46 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinParams p) {
   float bv[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) bv[jj] = (p.bias != nullptr && jj * 32 + l32 < p.nw) ? p.bias[jj * 32 + l32] : 0.f;
+  // whole tile, 64 real channels, no sigmoid (every launch of the step): packed f32 arithmetic, two pixels at a time,
+  // no per-element bounds checks; activation and statistics are compile-time there
+  const bool fast = ty0 + TH <= p.WH && tx0 + TW <= p.WW && p.nw == 64 && p.act != VG_ACT_SIGMOID;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int oy = ty0 + 2 * wave + i;
     const bool rowok = oy < p.WH;
+    if (fast) {
+      bf16_t* wlp = wt + 4 * h * 64 + l32;
+      auto lean = [&](auto LR, auto ST_) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          f32x2 a1 = f32x2{0.f, 0.f}, a2 = f32x2{0.f, 0.f};
+#pragma unroll
+          for (int r2 = 0; r2 < 8; ++r2) {
+            const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2);
+            f32x2 v = f32x2{acc[i][jj][r], acc[i][jj][r + 1]} + bv[jj];
+            bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+            if (decltype(ST_)::value || decltype(LR)::value) v = __builtin_convertvector(q, f32x2);
+            if (decltype(ST_)::value) { a1 += v; a2 += v * v; }
+            if (decltype(LR)::value) {
+              const f32x2 w = v * VG_LRELU_SLOPE;
+              f32x2 m;
+              asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
+              asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
+              q = __builtin_convertvector(m, bf16x2_t);
+            }
+            wlp[row * 64 + jj * 32] = q[0];
+            wlp[(row + 1) * 64 + jj * 32] = q[1];
+          }
+          if (decltype(ST_)::value) { s1[jj] += a1[0] + a1[1]; s2[jj] += a2[0] + a2[1]; }
+        }
+      };
+      typedef std::integral_constant<bool, true> Yes;
+      typedef std::integral_constant<bool, false> No;
+      if (p.act == VG_ACT_LRELU) { if (p.stats != nullptr) lean(Yes{}, Yes{}); else lean(Yes{}, No{}); }
+      else { if (p.stats != nullptr) lean(No{}, Yes{}); else lean(No{}, No{}); }
+    } else {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int n = jj * 32 + l32;
@@ -146,6 +183,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const ThinParams p) {
         if (n >= p.nw) v = 0.f;
         wt[col * 64 + n] = (bf16_t)v;
       }
+    }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
