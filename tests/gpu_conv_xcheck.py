@@ -58,11 +58,13 @@ def main(exit=True):
                     e = rel(a, b)
                     if not e <= tol:
                         print(f"MISMATCH v{mode} {nm} {shp} {str(dtype)[6:]} rel={e:.3e}", flush=True); bad += 1
-            e = rel(run_wgrad(lib, d, x, gy, 3), run_wgrad(lib, d, x, gy, 1))
-            if not e <= 2e-5:
-                print(f"MISMATCH wgrad {shp} {str(dtype)[6:]} rel={e:.3e}", flush=True); bad += 1
+            ref_w = run_wgrad(lib, d, x, gy, 1)
+            for wmode in (3, 4):                 # 64 x 64 slabs; 128 x 64 slabs where there are 128 output channels
+                e = rel(run_wgrad(lib, d, x, gy, wmode), ref_w)
+                if not e <= 2e-5:
+                    print(f"MISMATCH wgrad v{wmode} {shp} {str(dtype)[6:]} rel={e:.3e}", flush=True); bad += 1
     lib.vg_set_conv_kernel(3)
-    lib.vg_set_wgrad_kernel(3)
+    lib.vg_set_wgrad_kernel(4)
     print("mismatches:", bad)
     if exit:
         sys.exit(1 if bad else 0)

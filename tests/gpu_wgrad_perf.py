@@ -13,7 +13,7 @@ def run(n, h, w, ci, co, k, stride, pad, iters=5):
     flops = 2.0 * n * d.oh * d.ow * co * ci * k * k
     gb = (x.numel() + gy.numel()) * 2 / 1e9
     res = []
-    for mode in (1, 3):
+    for mode in (1, 3, 4):
         lib.vg_set_wgrad_kernel(mode)
         fn = lambda: lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, L.stream())
         fn(); torch.cuda.synchronize()
@@ -23,7 +23,7 @@ def run(n, h, w, ci, co, k, stride, pad, iters=5):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         res.append(f"v{mode} {ms:.3f}ms {flops/ms/1e9:.0f}TF {gb/ms*1e3:.0f}GB/s")
-    lib.vg_set_wgrad_kernel(3)
+    lib.vg_set_wgrad_kernel(4)
     print(f"{h}x{w} ci{ci} co{co} k{k}s{stride}: " + " | ".join(res), flush=True)
 
 for c in [(64, 256, 256, 64, 64, 3, 1, 1), (64, 128, 128, 128, 128, 3, 1, 1), (64, 64, 64, 256, 256, 3, 1, 1),

@@ -2490,7 +2490,7 @@ struct Wg3Cfg {
   static constexpr int STAGE = NOB * DYB + NCB * XB;
   static constexpr int NPIECE = NOB * DYP + NCB * XP;
   static constexpr int PR = (NPIECE + 7) / 8;                         // DMA pieces per wave per tile
-  static constexpr int NST = 3;
+  static constexpr int NST = 3 * STAGE <= 160 * 1024 ? 3 : 2;         // stages: the tile being read + NST - 1 in flight
   static constexpr int LDS = NST * STAGE;
   static constexpr int BO = 32 * NOB, BC = 32 * NCB;
 };
@@ -2588,7 +2588,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   {
     int img, ty0, tx0;
 #pragma unroll
-    for (int pre = 0; pre < 2; ++pre) {
+    for (int pre = 0; pre < NST - 1; ++pre) {
       if (g + pre * G < ntiles) {
         tile_pos(g + pre * G, img, ty0, tx0);
 #pragma unroll
@@ -2599,15 +2599,15 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   int stage = 0;
   for (; t < ntiles; t += G) {
     if (!VG_DBG(64)) {
-      if (t + G < ntiles) wait_vmcnt<PR>();
+      if (NST == 3 && t + G < ntiles) wait_vmcnt<PR>();              // the next tile's pieces may stay in flight
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
     }
     asm volatile("" ::: "memory");
-    const bool more = t + 2 * G < ntiles;
+    const bool more = t + (NST - 1) * G < ntiles;
     int nimg = 0, nty0 = 0, ntx0 = 0;
-    if (more) tile_pos(t + 2 * G, nimg, nty0, ntx0);
-    const int nstage = stage + 2 >= NST ? stage + 2 - NST : stage + 2;
+    if (more) tile_pos(t + (NST - 1) * G, nimg, nty0, ntx0);
+    const int nstage = stage + NST - 1 >= NST ? stage - 1 : stage + NST - 1;
     const unsigned char* sA = smem + stage * STAGE + abase;
     const unsigned char* sB = smem + stage * STAGE + bbase;
     // prefetch of tile t+2G, all of it before the tile's own work: the stream is latency-bound, and the earlier the
@@ -2885,7 +2885,7 @@ static int launch_wgrad3s2(const WgradParams& p0, hipStream_t st) {
   return VG_OK;
 }
 
-static int g_wgrad_kernel = 3;
+static int g_wgrad_kernel = 4;      // 1: per-tap kernel only; 3: + spatial-tile kernels with 64 x 64 slabs; 4: + 128 x 64 slabs (default)
 extern "C" void vg_set_wgrad_kernel(int version) { g_wgrad_kernel = version; }
 
 // Which spatial-tile configuration takes a weight gradient (0 = none: the per-tap kernel), and how many partial images
@@ -2906,6 +2906,7 @@ static Wg3Plan wg3_plan(const WgradParams& p, int R, int S, int dtype) {
     q.kind = 1; th = 4; tw = 32;
     if (p.Opad <= 32) { q.nob = 1; q.ncb = 2; q.ks = 4; }
     else if (p.Cpad <= 32) { q.nob = 2; q.ncb = 1; q.ks = 4; }
+    else if (g_wgrad_kernel >= 4 && p.Opad >= 128) { q.nob = 4; q.ncb = 2; q.ks = 1; }      // 128 x 64 slab, no row split
     else { q.nob = 2; q.ncb = 2; q.ks = 2; }
   } else {
     return q;
@@ -2921,6 +2922,7 @@ static int dispatch_wgrad3(const WgradParams& p, const Wg3Plan& q, hipStream_t s
     if (q.nob == 2) return launch_wgrad3s2<2, 1, 2>(p, st);
     return launch_wgrad3s2<1, 1, 4>(p, st);
   }
+  if (q.nob == 4) return launch_wgrad3<4, 2, 1>(p, st);
   if (q.nob == 1) return launch_wgrad3<1, 2, 4>(p, st);
   if (q.ncb == 1) return launch_wgrad3<2, 1, 4>(p, st);
   return launch_wgrad3<2, 2, 2>(p, st);
