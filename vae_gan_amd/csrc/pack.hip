@@ -103,23 +103,29 @@ extern "C" int vg_conv_pack_weight(const vg_conv_desc* d, int transposed, const 
 // 32 * RS consecutive master weights (coalesced; the packed order would read every RS-th float), turns them in LDS and
 // writes, per phase and tap, 32 rows of 32 consecutive packed elements.  Padding rows / columns are written as zeros.
 template <typename T> __global__ __launch_bounds__(256) void pack_batch_kernel(const PackParams* __restrict__ items) {
-  extern __shared__ float tile[];                      // [32][32 * bs + 1], bs = RS | 1 (odd strides: no bank conflicts)
+  extern __shared__ unsigned char tile_raw[];          // T [32][32 * bs + 2], bs = RS | 1; converted on the way in (half the LDS
+  T* tile = (T*)tile_raw;                               // for bf16: four blocks per CU instead of two)
   const PackParams& p = items[blockIdx.y];
-  const int RS = p.RS, bs = RS | 1, rowf = 32 * bs + 1;
+  const int RS = p.RS, bs = RS | 1, rowf = 32 * bs + 2;
   const int A = p.O, B = p.I;                           // master weights [A][B][RS]
   const int ctiles = (p.Cpad + 31) / 32, ntiles = ((p.Npad + 31) / 32) * ctiles;
   T* out = (T*)p.out;
   const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  __shared__ unsigned short lut[32 * 16];
+  for (int rem = threadIdx.x; rem < 32 * RS; rem += 256) lut[rem] = (unsigned short)((rem / RS) << 4 | (rem % RS));
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const int n0 = (t / ctiles) * 32, c0 = (t % ctiles) * 32;
     const int a0 = p.transposed ? c0 : n0, b0 = p.transposed ? n0 : c0;
     __syncthreads();
-    for (int i = threadIdx.x; i < 32 * 32 * RS; i += 256) {
-      const int a = i / (32 * RS), rem = i - a * (32 * RS);
-      const int b = rem / RS, rs = rem - b * RS;
-      float v = 0.f;
-      if (a0 + a < A && b0 + b < B) v = p.w[((size_t)(a0 + a) * B + b0) * RS + rem];
-      tile[a * rowf + b * bs + rs] = v;
+    for (int a = 0; a < 32; ++a) {                       // a row of 32 * RS consecutive master weights at a time
+      const bool arow = a0 + a < A;
+      const float* src = p.w + ((size_t)(a0 + a) * B + b0) * RS;
+      for (int rem = threadIdx.x; rem < 32 * RS; rem += 256) {
+        const int b = lut[rem] >> 4, rs = lut[rem] & 15;  // rem = b * RS + rs (no integer division per element)
+        float v = 0.f;
+        if (arow && b0 + b < B) v = src[rem];
+        tile[a * rowf + b * bs + rs] = Elt<T>::from_f(v);
+      }
     }
     __syncthreads();
     for (int ph = 0; ph < p.nphases; ++ph)
@@ -129,8 +135,8 @@ template <typename T> __global__ __launch_bounds__(256) void pack_batch_kernel(c
         for (int r = grp; r < 32; r += 8) {             // r: row of the packed tile (n), lane32: its column (c)
           const int n = n0 + r, c = c0 + lane32;
           if (n >= p.Npad || c >= p.Cpad) continue;
-          const float v = p.transposed ? tile[lane32 * rowf + r * bs + rs] : tile[r * rowf + lane32 * bs + rs];
-          out[(((size_t)ph * p.Npad + n) * p.ntaps + tap) * p.Cpad + c] = Elt<T>::from_f(v);
+          out[(((size_t)ph * p.Npad + n) * p.ntaps + tap) * p.Cpad + c] =
+              p.transposed ? tile[lane32 * rowf + r * bs + rs] : tile[r * rowf + lane32 * bs + rs];
         }
       }
   }
@@ -152,7 +158,7 @@ extern "C" int vg_conv_pack_batch(const void* items_dev, int n_items, int dtype,
   VG_REQUIRE(items_dev && n_items > 0 && n_items <= 65535, "pack_batch: bad arguments");
   VG_REQUIRE(dtype == VG_F32 || dtype == VG_BF16, "pack_batch: bad dtype %d", dtype);
   dim3 grid(256, n_items);                               // a block per 32 x 32 tile: 512 x 512 channels = 256 tiles
-  const size_t lds = (size_t)32 * (32 * 17 + 1) * sizeof(float);      // RS <= 16
+  const size_t lds = (size_t)32 * (32 * 17 + 2) * (dtype == VG_BF16 ? 2 : 4);      // RS <= 16
     VG_HIP(vg_lds_attr((const void*)pack_batch_kernel<bf16_t>, (int)lds));
     VG_HIP(vg_lds_attr((const void*)pack_batch_kernel<float>, (int)lds));
   if (dtype == VG_BF16) hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const PackParams*)items_dev);
