@@ -98,10 +98,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs MI355X GPUs (the HIP path has no CPU fallback)")
+    # VG_BENCH_SHARE_GPU=1: a rehearsal of the multi-rank path on a one-GPU box (every rank on cuda:0, gloo, gradients
+    # staged through the host); its numbers mean nothing.  The driver's runs use one GPU per rank over RCCL.
+    share = os.environ.get("VG_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from vae_gan_amd import ops
     from vae_gan_amd import train as T
