@@ -328,6 +328,15 @@ size_t vg_augment_ws_bytes(const vg_aug_item* items, int n, int out_h, int out_w
  * workspace and output are device memory. */
 int vg_augment_batch(const vg_aug_item* items, int n, int out_h, int out_w, void* ws, size_t ws_bytes, float* out, void* stream);
 
+/* Backward of a wide Linear layer y = x W^T + b (beta_vae_gans/model.py:126-127 fc_mu / fc_logvar: 131072.. 524288 input
+ * features, 128 outputs, a few dozen batch rows; all f32, row-major): one pass over the [fout][fin] matrix, no atomics.
+ *   vg_linear_wgrad: dw[o][k] (+= if accumulate) = sum_b gy[b][o] * x[b][k]
+ *   vg_linear_dgrad: dx[b][k] = sum_o gy[b][o] * w[o][k]
+ * fin must be even; fout * 128 bytes of LDS (fout <= 1280).  The generic pixel-reduction path (vg_conv_wgrad on a 1x1
+ * descriptor) stays for every other shape. */
+int vg_linear_wgrad(const float* x, const float* gy, float* dw, int b, int fin, int fout, int accumulate, void* stream);
+int vg_linear_dgrad(const float* gy, const float* w, float* dx, int b, int fin, int fout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1046,6 +1046,23 @@ class LinearFn(torch.autograd.Function):
         fout = weight.shape[0]
         bp = L.pad_channels(b, torch.float32)
         dx = dw = db = None
+        # wide layers (fc_mu / fc_logvar of the beta model: 524288 -> 128): one pass over the [fout][fin] matrix each
+        wide = fin >= 4096 and fin % 2 == 0 and fout * 128 <= 160 * 1024
+        if wide:
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty(b, fin, dtype=torch.float32, device=x.device)
+                L.check(lib.vg_linear_dgrad(gy.data_ptr(), weight.data_ptr(), dx.data_ptr(), b, fin, fout, L.stream()), "linear_dgrad")
+            if ctx.needs_input_grad[1]:
+                slot = _grad_slot(ctx.wparam)
+                dwt = slot if slot is not None else torch.empty(fout, fin, dtype=torch.float32, device=x.device)
+                L.check(_timed("linear_wgrad", 2.0 * b * fin * fout,
+                               lambda: lib.vg_linear_wgrad(x.data_ptr(), gy.data_ptr(), dwt.data_ptr(), b, fin, fout,
+                                                           int(slot is not None), L.stream()), ""), "linear_wgrad")
+                dw = None if slot is not None else dwt
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = torch.empty(fout, dtype=torch.float32, device=x.device)
+                L.check(lib.vg_colsum_f32(gy.data_ptr(), b, fout, db.data_ptr(), L.stream()), "linear.dbias")
+            return dx, dw, db
         if ctx.needs_input_grad[0]:
             # dx[b][k] = sum_o gy[b][o] W[o][k]: "pixels" = o; dy := gy^T [o][bp], x := W [o][fin]
             gyt = torch.empty(fout, bp, dtype=torch.float32, device=x.device)
