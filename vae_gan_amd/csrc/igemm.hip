@@ -675,10 +675,18 @@ struct Igemm3Cfg {
   static constexpr int BLANES = BN * 4 >= NT ? 64 : BN * 4 / 8;   // active lanes of one (BN = 64: half-masked)
   static constexpr int HS = 35, HSB = HS * 64, HH = TH + R - 1;   // halo image: HH rows of 35 pixels x 64 B
   static constexpr int HRN = (HH * HS * 4 + NT - 1) / NT;     // DMA rounds (512 x 16 B) per halo image
-  static constexpr int HBYTES = HRN * NT * 16;
   static constexpr int NSH = NTAPS >= PF + 1 + HRN ? 2 : 3;   // halo buffers
   static constexpr int HSTART = NSH == 2 ? PF + 1 : 0;        // first prefetch tap that carries a halo round
   static constexpr int WTILE = 32 * 32 * NI * EB;             // per-wave epilogue staging: one 32-row block
+  // a halo buffer is HRN whole DMA rounds, unless only the exact image (the last round partly masked off) lets the
+  // configuration fit: 16 x 32 px x 128 ch with 2x2 taps (three halo buffers) is 6 KB over otherwise
+  static constexpr int HPAD = HRN * NT * 16, HEXACT = HH * HS * 64;
+  static constexpr int lds_for(int hb) {
+    const int pipe = NSH * hb + NSB * BSTRIDE;
+    const int mainb = pipe > 8 * WTILE ? pipe : 8 * WTILE;
+    return mainb + BM * 4 + WM * BN * 2 * 4 + (mainb >= 8 * WTILE + 4 * BN * 4 ? 0 : 4 * BN * 4);
+  }
+  static constexpr int HBYTES = lds_for(HPAD) <= 160 * 1024 ? HPAD : HEXACT;
   static constexpr int PIPE = NSH * HBYTES + NSB * BSTRIDE;
   static constexpr int MAINB = PIPE > 8 * WTILE ? PIPE : 8 * WTILE;
   // [4][BN] f32 BatchNorm-backward coefficients (epilogue only): behind the epilogue staging tiles inside the then idle
@@ -769,7 +777,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       const long off = (((long)(img * p.H + row0) * p.W + col0) * p.Cs) * EB + (((ps ^ (hx >> 2)) & 3) << 4);
       if (m) o = (unsigned)(int)off;
       poff[rd] = o;
-      if (m == 0) {
+      if (m == 0 && q * 16 < HBYTES) {
 #pragma unroll
         for (int b = 0; b < NSH; ++b) *(u32x4*)(smem + b * HBYTES + q * 16) = u32x4{0, 0, 0, 0};
       }
@@ -778,7 +786,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       if (hy < HH && hx < TW + S - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
         o = (unsigned)((((size_t)(img * p.H + iy) * p.W + ix) * p.Cs) * EB) + (((ps ^ (hx >> 2)) & 3) << 4);
       poff[rd] = o;
-      if (o == 0xFFFFFFFFu) {
+      if (o == 0xFFFFFFFFu && q * 16 < HBYTES) {
 #pragma unroll
         for (int b = 0; b < NSH; ++b) *(u32x4*)(smem + b * HBYTES + q * 16) = u32x4{0, 0, 0, 0};
       }
