@@ -24,12 +24,12 @@ def run(n, h, w, ci, co, k, stride, pad):
     s = s[s[:, 0] > 0].double()
     dts = [(s[:, i + 1] - s[:, i]) for i in range(4)]
     names = ["launch->prologue landed", "main loop", "epilogue (stores issued)", "stats+tail"]
-    print(f"{h}x{w} ci{ci} co{co} k{k}s{stride}: blocks {s.shape[0]}, memtime ticks (100 MHz => x10 ns):")
+    print(f"{h}x{w} ci{ci} co{co} k{k}s{stride}: blocks {s.shape[0]}, s_memtime ticks:")
     for nm, v in zip(names, dts):
         print(f"   {nm:28s} mean {v.mean():9.1f} median {v.median():9.1f}")
     print(f"   block lifetime (stamp0..4) mean {(s[:,4]-s[:,0]).mean():9.1f}; kernel span {(s[:,4].max()-s[:,0].min()):9.1f}")
     lib.vg_dbg_set_stamp_buffer(None)
     lib.vg_set_conv_kernel(3)
 
-for c in [(64, 256, 256, 64, 64, 3, 1, 1), (64, 128, 128, 128, 128, 3, 1, 1), (64, 32, 32, 512, 512, 3, 1, 1)]:
+for c in [(64, 64, 64, 256, 256, 3, 1, 1), (64, 32, 32, 512, 512, 3, 1, 1)]:
     run(*c)

@@ -668,7 +668,7 @@ struct Igemm3Cfg {
   static constexpr int NT = 512, TW = 32, TH = MI * WM, BM = TH * TW, BN = 32 * NI * WN;
   static constexpr int EB = sizeof(T), KC = 64 / EB, PIECE = 16 / EB;
   static constexpr int NTAPS = R * S, PF = 3, NSB = PF + 2;
-  static constexpr int NPH = (MI * NI == 8) ? 2 : 1;          // phases per K tile, 8 MFMA blocks each
+  static constexpr int NPH = (MI * NI == 8) ? 2 : 1;          // phases per K tile, 8 MFMA blocks each (16 per phase: no faster)
   static constexpr int KPP = 2 / NPH;                         // 16-byte fragment steps per phase
   static constexpr int BSTRIDE = BN * 64;
   static constexpr int LPB = (BN * 4 + NT - 1) / NT;          // weight DMA instructions per wave per K tile
@@ -1951,6 +1951,13 @@ template <typename T> static int dispatch_igemm4(const IgemmParams& p, hipStream
 }
 
 template <typename T, int R, int S> static int dispatch_igemm3_rs(const IgemmParams& p, hipStream_t st, bool* handled) {
+  // >= 256 output channels: 16x32 px x 128 ch tiles (two or more channel blocks per pixel tile) stream a third less through
+  // the LDS-DMA per MFMA than 8x32 px x 256 ch (8 KB of weights + 4.5 KB of halo per K tile against 16 + 2.5): +3 % on the
+  // 256- and 512-channel layers (tests/gpu_conv_perf2.py; VG_IGEMM3_WIDE_TILE=1 keeps the 256-channel tile)
+  static const bool wide = getenv("VG_IGEMM3_WIDE_TILE") != nullptr && atoi(getenv("VG_IGEMM3_WIDE_TILE")) != 0;
+  if constexpr (Igemm3Cfg<T, 4, 2, 4, 2, R, S>::FITS) {
+    if (!wide && p.Npad % 256 == 0 && p.OHl % 16 == 0) return launch_igemm3<T, 4, 2, 4, 2, R, S>(p, st, handled);
+  }
   if (p.Npad % 256 == 0) return launch_igemm3<T, 4, 2, 2, 4, R, S>(p, st, handled);   // 8x32 px x 256 ch
   if (p.Npad == 128) {
     if constexpr (Igemm3Cfg<T, 4, 2, 4, 2, R, S>::FITS) return launch_igemm3<T, 4, 2, 4, 2, R, S>(p, st, handled);   // 16x32 px x 128 ch

@@ -482,6 +482,15 @@ class Conv2dFn(torch.autograd.Function):
                            lambda: lib.vg_thin_conv_fwd(C.byref(d), x.data_ptr(), w32.data_ptr(), L.ptr(bias), y.data_ptr(),
                                                         L.ptr(stats), act, tws.data_ptr(), L.stream()), _shape_tag("fwd", d)),
                     "thin_conv_fwd")
+        elif (co <= 32 and not want_stats and dt == torch.bfloat16 and not deterministic()
+              and n * d.oh * d.ow <= 32768 and k * k * xcs >= 2048):
+            # few output tiles, a long reduction (the PatchGAN tail, 512 -> 1 4x4 on 16x16: 57 tiles of 256 K steps):
+            # the K dimension split over blocks, partial sums meet in an f32 workspace (91 -> ~20 us)
+            wp = packs.get(weight, d, 0, dt)
+            ws = torch.empty(lib.vg_conv_splitk_ws_bytes(C.byref(d)) // 4, dtype=torch.float32, device=x.device)
+            L.check(_timed(None, _conv_flops(d),
+                           lambda: lib.vg_conv_fwd_splitk(C.byref(d), x.data_ptr(), wp.data_ptr(), L.ptr(bias), y.data_ptr(),
+                                                          act, 0, ws.data_ptr(), L.stream()), _shape_tag("fwd", d)), "conv_fwd_splitk")
         else:
             wp = packs.get(weight, d, 0, dt)
             L.check(_timed(None, _conv_flops(d),
