@@ -836,6 +836,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
     } else {
       src = wg + ((size_t)itap * cbytes + (size_t)icc * 64) + boff[i];
     }
+    if (VG_DBG(16)) src = wg + boff[i];        // timing ablation: every weight tile from the same (cache-hot) 8-16 KB
     unsigned char* dst = smem + SB_OFF + slot * BSTRIDE + (i * NT + wave * BLANES) * 16;
     if (BLANES == 64 || lane < BLANES) __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
   };
@@ -868,37 +869,47 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
 #pragma unroll
   for (int t0 = 0; t0 < PF; ++t0) {
 #pragma unroll
-    for (int i = 0; i < LPB; ++i) dma_b(i, t0, 0, t0);
+    for (int i = 0; i < LPB; ++i) dma_b(i, (t0 % R) * S + t0 / R, 0, t0);
     halo_rounds(t0, 1, NSH > 1 ? HBYTES : 0);
   }
   __syncthreads();                                   // drains the prologue DMA once; zero fill and rowpix visible
   VG_STAMP(1);
   if (group == 1 && !VG_DBG(2)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
 
+  const int wrow0 = (wm * MI + (flip ? R + MI - 2 : 0)) * HSB;     // window slot 0, and the step to the next slot
+  const int wstep = flip ? -HSB : HSB;
   int cbs = 0;                         // weight slot of the tile being computed
   int hb0 = 0;                         // halo buffer offset of the chunk being computed
   for (int cc = 0; cc < cchunks; ++cc) {
     const int hb1 = hb0 + HBYTES == NSH * HBYTES ? 0 : hb0 + HBYTES;     // chunk cc+1
     const int hb2 = hb1 + HBYTES == NSH * HBYTES ? 0 : hb1 + HBYTES;     // chunk cc+2
     const int wcc = cc + 1 < cchunks ? cc + 1 : 0;   // weights prefetched past the end re-read chunk 0 (never consumed)
+    // The taps are walked COLUMN by column (step sq = s*R + r): the R taps of a column need the A rows r .. r+MI-1 of
+    // the same shifted halo image, so a window of R+MI-1 row fragments per k half stays in registers and every step after
+    // the first of a column reads ONE new row instead of MI (3x3, MI = 4: 4 LDS reads per 8 MFMAs instead of 6).
+    // Window slot u is halo row u, or R+MI-2-u when the taps run high to low (flip): the set a step needs is
+    // u = r .. r+MI-1 either way, and accumulator i then belongs to output row MI-1-i (undone in the epilogue).
+    u32x4 win[2][R + MI - 1];
 #pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
-      const int r = tap / S, s = tap % S;
-      const int itap = (tap + PF) % NTAPS;           // tile the prefetch of this step belongs to
-      const bool wrap = tap + PF >= NTAPS;
+    for (int sq = 0; sq < NTAPS; ++sq) {
+      const int s = sq / R, r = sq % R;
+      const int isq = (sq + PF) % NTAPS;             // step the prefetch of this step belongs to
+      const int itap = (isq % R) * S + isq / R;      // ... and its tap in the packed weights
+      const bool wrap = sq + PF >= NTAPS;
       const int ibs = cbs + PF >= NSB ? cbs + PF - NSB : cbs + PF;
-      const int va0 = ct[s] + hb0 + (wm * MI + (flip ? R - 1 - r : r)) * HSB;
+      const int va0 = ct[s] + hb0 + wrow0;
       const int vb0 = bfo + cbs * BSTRIDE;
 #pragma unroll
       for (int ph = 0; ph < NPH; ++ph) {
-        u32x4 fa[KPP][MI], fb[KPP][NI];
+        u32x4 fb[KPP][NI];
         // ---- memory part: fragments of this phase, DMA prefetch, retire the next tile's DMA
 #pragma unroll
         for (int kk = 0; kk < KPP; ++kk) {
           const int j = ph * KPP + kk;
-          const int va = VG_DBG(4) ? 0 : (j ? va0 ^ 32 : va0), vb = VG_DBG(4) ? 0 : (j ? vb0 ^ 32 : vb0);
+          const int va = j ? va0 ^ 32 : va0, vb = VG_DBG(4) ? 0 : (j ? vb0 ^ 32 : vb0);
 #pragma unroll
-          for (int i = 0; i < MI; ++i) fa[kk][i] = *(const u32x4*)(smem + va + i * HSB);
+          for (int u = (r == 0 ? 0 : r + MI - 1); u < r + MI; ++u)
+            win[j][u] = *(const u32x4*)(smem + (VG_DBG(4) ? 0 : va + u * wstep));
 #pragma unroll
           for (int jj = 0; jj < NI; ++jj) fb[kk][jj] = *(const u32x4*)(smem + vb + jj * 2048);
         }
@@ -906,7 +917,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
 #pragma unroll
           for (int i = 0; i < LPB; ++i)
             if (i % NPH == ph) dma_b(i, itap, wrap ? wcc : cc, ibs);
-          if (ph == NPH - 1) halo_rounds(itap, wrap ? cc + 2 : cc + 1, wrap ? hb2 : hb1);
+          if (ph == NPH - 1) halo_rounds(isq, wrap ? cc + 2 : cc + 1, wrap ? hb2 : hb1);
         }
         if (ph == NPH - 1 && !VG_DBG(2)) wait_vmcnt<(PF - 1) * LPB>();
         if (!VG_DBG(2)) __builtin_amdgcn_s_barrier();
@@ -917,7 +928,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int jj = 0; jj < NI; ++jj) acc[i][jj] = Mma<T>::run(fa[kk][i], fb[kk][jj], acc[i][jj]);
+            for (int jj = 0; jj < NI; ++jj) acc[i][jj] = Mma<T>::run(win[ph * KPP + kk][r + i], fb[kk][jj], acc[i][jj]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (!VG_DBG(2)) __builtin_amdgcn_s_barrier();
@@ -972,7 +983,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   constexpr int ROUNDS = 32 * PPR / 64;          // store rounds of one 32-row block: 16-byte piece lane + 64*rd
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const unsigned* rp = rowpix + (wm * MI + i) * 32;
+    const unsigned* rp = rowpix + (wm * MI + (flip ? MI - 1 - i : i)) * 32;    // see the A window of the main loop
     // BatchNorm-backward sums: this block's pieces of the raw BatchNorm input (and of its output when the mask comes
     // from there) are requested NOW, before the accumulators are converted and staged, so that their memory latency
     // runs under that work (loaded right where they are used, every store round stalled for a full latency)
