@@ -11,6 +11,9 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int c, int 
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch == 0 && num_batches != nullptr) *num_batches += updates;
   if (ch >= c) return;
+  // everything this thread reads is requested before the sums are used: one memory latency for the whole kernel
+  const float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
+  const float rm0 = running_mean ? running_mean[ch] : 0.f, rv0 = running_mean ? running_var[ch] : 0.f;
   const double s1 = vg_stats_read(stats, cpad, 0, ch, det), s2 = vg_stats_read(stats, cpad, 1, ch, det);
   double m = s1 / count;
   double var = s2 / count - m * m;
@@ -18,13 +21,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int c, int 
   float is = (float)(1.0 / sqrt(var + (double)eps));
   mean[ch] = (float)m;
   invstd[ch] = is;
-  float g = gamma ? gamma[ch] : 1.f, b = beta ? beta[ch] : 0.f;
   float sc = g * is;
   scale[ch] = sc;
   shift[ch] = b - (float)m * sc;
   if (running_mean != nullptr) {
     double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    float rm = running_mean[ch], rv = running_var[ch];
+    float rm = rm0, rv = rv0;
     for (int u = 0; u < updates; ++u) {
       rm = (1.f - momentum) * rm + momentum * (float)m;
       rv = (1.f - momentum) * rv + momentum * (float)unbiased;
@@ -282,21 +284,24 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
                                    float* dgamma, float* dbeta, int accumulate, float dgb_scale, float* dxsum, int det) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= c) return;
+  const float gm = gamma ? gamma[ch] : 1.f, is = invstd[ch], mu = mean[ch];     // requested before the sums are used
+  const float dg0 = (dgamma && accumulate) ? dgamma[ch] : 0.f, db0 = (dbeta && accumulate) ? dbeta[ch] : 0.f;
+  const float dxs0 = dxsum ? dxsum[ch] : 0.f;
   const double s1 = vg_stats_read(sums, cpad, 0, ch, det), s2 = vg_stats_read(sums, cpad, 1, ch, det);
   // d = a*(dz - m1 - xh*m2), xh = (x-mu)*is  ==  a*dz - (a*m1 - a*m2*is*mu) - (a*m2*is)*x
-  const float a = (gamma ? gamma[ch] : 1.f) * invstd[ch], m1 = (float)(s1 / count), m2 = (float)(s2 / count);
-  const float cx = a * m2 * invstd[ch];
+  const float a = gm * is, m1 = (float)(s1 / count), m2 = (float)(s2 / count);
+  const float cx = a * m2 * is;
   coef[ch] = a;
-  coef[cpad + ch] = a * m1 - cx * mean[ch];
+  coef[cpad + ch] = a * m1 - cx * mu;
   coef[2 * cpad + ch] = cx;
   const float g2 = (float)(s2 * (double)dgb_scale), g1 = (float)(s1 * (double)dgb_scale);
-  if (dgamma) dgamma[ch] = accumulate ? dgamma[ch] + g2 : g2;
-  if (dbeta) dbeta[ch] = accumulate ? dbeta[ch] + g1 : g1;
+  if (dgamma) dgamma[ch] = dg0 + g2;
+  if (dbeta) dbeta[ch] = db0 + g1;
   // Per-channel sum of dx (the bias gradient of the conv in front of this BatchNorm) in closed form, when the sums are
   // those of the rows this rank holds (count = rows):  sum dx = ca*S1 - rows*cb - cx*Sx  with Sx = rows*mean collapses to
   // a*(S1 - rows*m1).  Mathematically zero; what is left is the rounding of m1 to float, i.e. the same kind of noise the
   // reference's autograd leaves there, but without a pass over dx, without atomics, and reproducible.
-  if (dxsum) dxsum[ch] += (float)((double)a * (s1 - count * (double)m1));
+  if (dxsum) dxsum[ch] = dxs0 + (float)((double)a * (s1 - count * (double)m1));
 }
 
 template <typename T, bool HAS_DRES, bool XMASK>

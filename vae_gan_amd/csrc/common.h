@@ -120,16 +120,22 @@ __device__ inline void vg_acc_add(double* slot0, size_t rep_stride, unsigned hin
   }
 }
 __device__ inline double vg_acc_read(const double* slot0, size_t rep_stride, int det) {
+  // all loads first (the finalize kernels are one memory latency long, not 32), then the sum in a fixed order
   double s = 0.0;
   if (!det) {
-    for (int r = 0; r < VG_STATS_REPLICAS; ++r) s += slot0[(size_t)r * rep_stride];
+    double v[VG_STATS_REPLICAS];
+#pragma unroll
+    for (int r = 0; r < VG_STATS_REPLICAS; ++r) v[r] = slot0[(size_t)r * rep_stride];
+#pragma unroll
+    for (int r = 0; r < VG_STATS_REPLICAS; ++r) s += v[r];
     return s;
   }
   const long long* q = (const long long*)slot0;
-  for (int b = VG_DET_BINS - 1; b >= 0; --b) {
-    const long long t = q[(size_t)b * rep_stride] + q[(size_t)(b + VG_DET_BINS) * rep_stride];
-    s += ldexp((double)t, 24 * b - 150);
-  }
+  long long t[VG_DET_BINS];
+#pragma unroll
+  for (int b = 0; b < VG_DET_BINS; ++b) t[b] = q[(size_t)b * rep_stride] + q[(size_t)(b + VG_DET_BINS) * rep_stride];
+#pragma unroll
+  for (int b = VG_DET_BINS - 1; b >= 0; --b) s += ldexp((double)t[b], 24 * b - 150);
   return s;
 }
 // the [VG_STATS_REPLICAS][2][cpad] layout of the BatchNorm sums (which: 0 = first sum, 1 = second)
