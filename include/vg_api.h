@@ -116,6 +116,9 @@ typedef struct vg_bn_bwd_stats {
   double* sums;
   int cpad;
   int act;
+  int mask_out; /* != 0: a launch that fuses stores dz = dout * act'(.) instead of dout (rounded to the tensor's dtype;
+                   the sums are those of the stored values): the BatchNorm backward then runs vg_bn_bwd_apply with
+                   act = VG_ACT_NONE and y = NULL, and a residual BatchNorm's skip gradient is that tensor itself */
 } vg_bn_bwd_stats;
 int vg_conv_dgrad_bnstats(const vg_conv_desc* d, const void* dy, const void* w_packed_t, void* dx, int accumulate,
                           const vg_bn_bwd_stats* bs, int* fused, void* stream);
@@ -193,6 +196,13 @@ int vg_bn_act_fwd(const void* x, const void* res, void* y, const float* scale, c
 int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                      const float* scale, const float* shift, double* sums, int64_t rows, int cs, int c, int cpad,
                      int act, int dtype, void* stream);
+/* vg_bn_bwd_reduce that also writes the masked gradient dz = dout * act'(.) (dz may be dout: in place) and sums the
+ * values as stored.  For a residual BatchNorm (the tail of ResidualBlock, vq_vae_gan/model.py:24-27: out = lrelu(bn2(.) +
+ * x)) the apply pass then reads two tensors instead of three and writes one instead of two: vg_bn_bwd_apply(dout = dz,
+ * y = NULL, act = VG_ACT_NONE, dres = NULL), the skip gradient being dz. */
+int vg_bn_bwd_reduce_dz(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+                        const float* scale, const float* shift, double* sums, void* dz, int64_t rows, int cs, int c,
+                        int cpad, int act, int dtype, void* stream);
 /* Backward, pass 2: dx = gamma*invstd*(dz - sum_dz/n - xhat*sum_dzxhat/n); dres = dz (optional);
  * dgamma = sum_dzxhat, dbeta = sum_dz (f32 [c]). */
 /* NOTE: `sums` must be followed by 3*cpad f32 of scratch (coefficients), i.e. allocate

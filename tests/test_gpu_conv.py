@@ -126,6 +126,72 @@ def test_dgrad_bnstats_matches_separate_reduce(gpu, case):
     assert float(b[:, ci:].abs().max()) == 0.0 if cpad > ci else True
 
 
+@pytest.mark.parametrize("case", [(4, 64, 64, 128, 128, 3, 1, 1, 0), (2, 64, 64, 256, 256, 3, 1, 1, 0), (2, 32, 32, 256, 512, 3, 1, 1, 1), (2, 64, 64, 64, 128, 4, 2, 1, 0),
+                                  (2, 40, 36, 128, 64, 3, 1, 1, 1)],
+                         ids=lambda c: "n%d_%dx%d_ci%d_co%d_k%ds%dp%d_acc%d" % c)
+def test_dgrad_bnstats_mask_out_stores_masked_gradient(gpu, case):
+    """vg_bn_bwd_stats.mask_out: the fused launch stores dz = dx * LeakyReLU'(y) instead of dx.  Bits equal to
+    vg_bn_bwd_reduce_dz run on the plain vg_conv_dgrad output, and so are the sums (those of the stored values); the
+    BatchNorm backward that follows (vg_bn_bwd_apply on dz, act NONE, no y) matches the three-tensor apply pass."""
+    import ctypes as C
+    from vae_gan_amd import lib as L
+    n, h, w, ci, co, k, stride, pad, acc = case
+    lib = L.load()
+    dt = torch.bfloat16
+    d = G.make_desc(n, h, w, ci, co, k, stride, pad, dt)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    wt = (torch.randn(co, ci, k, k, device="cuda", generator=g) / (ci * k * k) ** 0.5).contiguous()
+    wpt = G.pack(lib, d, wt, 1, dt)
+    gy = torch.randn(n, d.oh, d.ow, d.ycs, device="cuda", generator=g).to(dt)
+    xraw = torch.randn(n, h, w, d.xcs, device="cuda", generator=g).to(dt)
+    ybn = torch.randn(n, h, w, d.xcs, device="cuda", generator=g).to(dt)
+    parked = torch.randn(n, h, w, d.xcs, device="cuda", generator=g).to(dt)
+    mean, invstd, scale, shift = _bn_vec(ci, 0, 5)
+    gamma = torch.rand(ci, device="cuda", generator=g) + 0.5
+    cpad, rows = ci, n * h * w
+    nsum = L.STATS_REPLICAS * 2 * cpad
+    dx0 = parked.clone()
+    L.check(lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx0.data_ptr(), None, L.ACT_NONE, acc, L.stream()), "dgrad")
+    want = torch.zeros(nsum + 2 * cpad, dtype=torch.float64, device="cuda")
+    dz0 = torch.empty_like(dx0)
+    L.check(lib.vg_bn_bwd_reduce_dz(dx0.data_ptr(), ybn.data_ptr(), xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                    scale.data_ptr(), shift.data_ptr(), want.data_ptr(), dz0.data_ptr(), rows, d.xcs, ci, cpad,
+                                    L.ACT_LRELU, L.VG_BF16, L.stream()), "bn_bwd_reduce_dz")
+    ref = torch.where(ybn.float() > 0, dx0.float(), dx0.float() * 0.2).to(dt)
+    assert torch.equal(dz0, ref)
+    dx1 = parked.clone()
+    got = torch.zeros_like(want)
+    bs = L.BnBwdStats(x=xraw.data_ptr(), y=ybn.data_ptr(), mean=mean.data_ptr(), invstd=invstd.data_ptr(), scale=scale.data_ptr(),
+                      shift=shift.data_ptr(), sums=got.data_ptr(), cpad=cpad, act=L.ACT_LRELU, mask_out=1)
+    fused = C.c_int(-1)
+    L.check(lib.vg_conv_dgrad_bnstats(C.byref(d), gy.data_ptr(), wpt.data_ptr(), dx1.data_ptr(), acc, C.byref(bs),
+                                      C.byref(fused), L.stream()), "dgrad_bnstats")
+    torch.cuda.synchronize()
+    if fused.value == 0:      # weights-stationary kernels: no fused sums, and the gradient is stored unmasked
+        assert lib.vg_last_conv_kernel().startswith(b"igemm4") and torch.equal(dx1, dx0), lib.vg_last_conv_kernel()
+        return
+    assert fused.value == 1, lib.vg_last_conv_kernel()
+    assert torch.equal(dx1, dz0)
+    a = want[:nsum].view(L.STATS_REPLICAS, 2, cpad).sum(0)
+    b = got[:nsum].view(L.STATS_REPLICAS, 2, cpad).sum(0)
+    scale_ = a.abs().max(dim=1, keepdim=True).values
+    assert float(((a - b).abs() / scale_).max()) <= 2e-6
+    # the apply pass on the masked gradient against the three-tensor pass on the raw one (same sums)
+    dxa, dxb, dres = torch.empty_like(dx0), torch.empty_like(dx0), torch.empty_like(dx0)
+    dg = torch.zeros(4, ci, device="cuda")
+    L.check(lib.vg_bn_bwd_apply(dx0.data_ptr(), ybn.data_ptr(), xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                shift.data_ptr(), gamma.data_ptr(), want.data_ptr(), dxa.data_ptr(), dres.data_ptr(), dg[0].data_ptr(),
+                                dg[1].data_ptr(), 0, None, rows, rows, 1.0, d.xcs, ci, cpad, L.ACT_LRELU, L.VG_BF16, L.stream()), "apply")
+    L.check(lib.vg_bn_bwd_apply(dx1.data_ptr(), None, xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                                shift.data_ptr(), gamma.data_ptr(), got.data_ptr(), dxb.data_ptr(), None, dg[2].data_ptr(),
+                                dg[3].data_ptr(), 0, None, rows, rows, 1.0, d.xcs, ci, cpad, L.ACT_NONE, L.VG_BF16, L.stream()), "apply")
+    torch.cuda.synchronize()
+    assert torch.equal(dres, dz0)                    # the skip gradient of the old pass is the masked tensor
+    rel = float((dxa.float() - dxb.float()).norm() / dxa.float().norm())
+    assert rel <= 4e-3, rel                          # one more bf16 rounding of 0.2 * dout on the masked elements
+    assert float((dg[0] - dg[2]).abs().max() / dg[0].abs().max()) <= 1e-5 and float((dg[1] - dg[3]).abs().max() / dg[1].abs().max()) <= 1e-5
+
+
 def test_dgrad_bnstats_reports_unfused_kernels(gpu):
     """Kernel variants without the fused sums (f32 parity mode, narrow images) leave the sums alone and say so."""
     import ctypes as C

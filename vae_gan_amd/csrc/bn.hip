@@ -162,12 +162,16 @@ extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const floa
 // ---------------------------------------------------------------------------------------------
 // XMASK: the LeakyReLU mask is recomputed from x with the forward pass's own scale/shift (same expression, same
 // rounding) instead of being read back from y: one tensor pass less.
-template <typename T, bool XMASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+// WRITE_DZ: the masked gradient dz = dout * act'(.) is also written out (dzout may be dout itself: every element is read
+// and written by the same thread), and the sums are those of the value as stored.  The apply pass then needs neither y nor
+// the mask, and a residual BatchNorm's skip gradient IS that tensor (see vg_bn_bwd_reduce_dz).
+template <typename T, bool XMASK, bool WRITE_DZ = false>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* __restrict__ y,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, double* __restrict__ sums,
-                                                            int64_t rows, int cs, int c, int cpad, int act, int det) {
+                                                            int64_t rows, int cs, int c, int cpad, int act, int det,
+                                                            T* dzout = nullptr) {
   constexpr int PIECE = Elt<T>::PIECE;
   __shared__ float red[256 * PIECE * 2];
   const int ppr = cs / PIECE;                        // pieces per row (<= 256 guaranteed by launcher)
@@ -187,16 +191,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int e = 0; e < PIECE; ++e) { d1[e] = 0.0; d2[e] = 0.0; }
   if (rr < rpb) {
     int cnt = 0;
-    auto take = [&](const Piece<T>& g, const Piece<T>& o, const Piece<T>& v) {
+    auto take = [&](const Piece<T>& g, const Piece<T>& o, const Piece<T>& v, size_t off) {
+      Piece<T> m;
 #pragma unroll
       for (int e = 0; e < PIECE; ++e) {
         float dz = g.get(e);
         const float yv = XMASK ? v.get(e) * sc[e] + sh[e] : o.get(e);
         if (act == VG_ACT_LRELU && !(yv > 0.f)) dz *= VG_LRELU_SLOPE;
+        if (WRITE_DZ) { m.set(e, dz); dz = m.get(e); }
         const float xh = (v.get(e) - mu[e]) * is[e];
         a1[e] += dz;
         a2[e] += dz * xh;
       }
+      if (WRITE_DZ) *(decltype(m.v)*)(dzout + off) = m.v;
       if (++cnt == 32) {
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) { d1[e] += a1[e]; d2[e] += a2[e]; a1[e] = 0.f; a2[e] = 0.f; }
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         v[u].v = *(const decltype(v[u].v)*)(x + off);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) take(g[u], o[u], v[u]);
+      for (int u = 0; u < U; ++u) take(g[u], o[u], v[u], (size_t)(r + u * stride) * cs + pc * PIECE);
     }
     for (; r < rend; r += stride) {
       const size_t off = (size_t)r * cs + pc * PIECE;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       g.v = *(const decltype(g.v)*)(dout + off);
       if (!XMASK) o.v = *(const decltype(o.v)*)(y + off);
       v.v = *(const decltype(v.v)*)(x + off);
-      take(g, o, v);
+      take(g, o, v, off);
     }
   }
   // combine the rpb row-groups of this block through LDS, then one f64 atomic per channel per block
@@ -247,9 +254,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   }
 }
 
-extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+static int bn_bwd_reduce_launch(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
                                 const float* scale, const float* shift, double* sums, int64_t rows, int cs, int c, int cpad,
-                                int act, int dtype, void* stream) {
+                                int act, int dtype, void* dz, void* stream) {
   VG_REQUIRE(dout && x && mean && invstd && sums && rows > 0 && cs >= c && cpad >= c, "bn_bwd_reduce: bad arguments");
   VG_REQUIRE(y || (scale && shift), "bn_bwd_reduce: need y, or scale and shift to recompute the activation mask from x");
   const bool xmask = y == nullptr && act == VG_ACT_LRELU;
@@ -263,6 +270,16 @@ extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, 
   if (y == nullptr && !xmask) y = x;    // no activation: the value is never looked at
   const int det = vg_det_mode();
   dim3 g((unsigned)blocks), b(256);
+  if (dz != nullptr) {
+#define VG_BN_REDUCE_DZ(T, XM)                                                                                           \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, XM, true>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
+                     scale, shift, sums, rows, cs, c, cpad, act, det, (T*)dz)
+    if (dtype == VG_BF16) { if (xmask) VG_BN_REDUCE_DZ(bf16_t, true); else VG_BN_REDUCE_DZ(bf16_t, false); }
+    else { if (xmask) VG_BN_REDUCE_DZ(float, true); else VG_BN_REDUCE_DZ(float, false); }
+#undef VG_BN_REDUCE_DZ
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   if (dtype == VG_BF16) {
     if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
     else hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
@@ -272,6 +289,18 @@ extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, 
   }
   VG_LAUNCH_CHECK();
   return VG_OK;
+}
+
+extern "C" int vg_bn_bwd_reduce(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+                                const float* scale, const float* shift, double* sums, int64_t rows, int cs, int c, int cpad,
+                                int act, int dtype, void* stream) {
+  return bn_bwd_reduce_launch(dout, y, x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, dtype, nullptr, stream);
+}
+extern "C" int vg_bn_bwd_reduce_dz(const void* dout, const void* y, const void* x, const float* mean, const float* invstd,
+                                   const float* scale, const float* shift, double* sums, void* dz, int64_t rows, int cs, int c,
+                                   int cpad, int act, int dtype, void* stream) {
+  VG_REQUIRE(dz != nullptr, "bn_bwd_reduce_dz: dz is required");
+  return bn_bwd_reduce_launch(dout, y, x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, dtype, dz, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,7 +424,8 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   VG_REQUIRE(dout && x && mean && invstd && sums && dx && rows > 0 && cs >= c && cpad >= c, "bn_bwd_apply: bad arguments");
   VG_REQUIRE(y || (scale && shift), "bn_bwd_apply: need y, or scale and shift to recompute the activation mask from x");
   VG_REQUIRE(y || act == VG_ACT_LRELU || act == VG_ACT_NONE, "bn_bwd_apply: y is required for this activation");
-  const bool xmask = y == nullptr && act == VG_ACT_LRELU;
+  // no activation and no y: the kernel variant without the y load (its recomputed mask value is never looked at)
+  const bool xmask = y == nullptr && (act == VG_ACT_LRELU || (scale && shift));
   if (y == nullptr && !xmask) y = x;
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "bn_bwd_apply: channel stride %d unsupported", cs);

@@ -1067,19 +1067,21 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) o.set(e, o.get(e) + old.get(e));
       }
-      *(decltype(o.v)*)dst = o.v;
       if (bs) {        // o = the gradient as stored (what the BatchNorm backward will read)
         const float* cf = coef + wn * WN_COLS + pc * PIECE;
+        const bool mask_out = p.bs.mask_out != 0;       // store dz (the masked gradient) instead of dout
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) {
           const float xf = xr[rd].get(e);
           float dz = o.get(e);
           const float pre = p.bs.y != nullptr ? yr[rd].get(e) : xf * cf[e] + cf[BN + e];
           if (p.bs.act == VG_ACT_LRELU && !(pre > 0.f)) dz *= VG_LRELU_SLOPE;
+          if (mask_out) { o.set(e, dz); dz = o.get(e); }    // the sums are those of the value as stored
           bs1[e] += dz;
           bs2[e] += dz * (xf * cf[2 * BN + e] - cf[3 * BN + e]);
         }
       }
+      *(decltype(o.v)*)dst = o.v;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();

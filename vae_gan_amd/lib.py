@@ -36,7 +36,7 @@ _DP = C.POINTER(ConvDesc)
 
 class BnBwdStats(C.Structure):
     """vg_bn_bwd_stats of include/vg_api.h."""
-    _fields_ = [(n, C.c_void_p) for n in ("x", "y", "mean", "invstd", "scale", "shift", "sums")] + [("cpad", C.c_int), ("act", C.c_int)]
+    _fields_ = [(n, C.c_void_p) for n in ("x", "y", "mean", "invstd", "scale", "shift", "sums")] + [("cpad", C.c_int), ("act", C.c_int), ("mask_out", C.c_int)]
 
 
 class AugItem(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "vg_channel_stats": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "vg_bn_bwd_reduce_dz": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _L, _L, _F, _I, _I, _I, _I, _I, _P]),
     "vg_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "vg_add_inplace": (_I, [_P, _P, _L, _I, _P]),

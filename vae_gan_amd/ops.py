@@ -403,12 +403,12 @@ class BwdStatLink:
     two-tensor reduction pass.  The link rides on the BatchNorm's output tensor (``_vg_bwdstat``) and is only used
     when a container that knows the topology armed it (FusedSequential: element k feeds element k+1 and nothing
     else; ResidualBlock: bn1 feeds conv2) and exactly one convolution claimed it."""
-    __slots__ = ("x", "y", "vec", "c", "cpad", "act", "armed", "claims", "sums", "fused")
+    __slots__ = ("x", "y", "vec", "c", "cpad", "act", "armed", "claims", "sums", "fused", "masked")
 
     def __init__(self):
         self.x = self.y = self.vec = self.sums = None
         self.c = self.cpad = self.act = 0
-        self.armed, self.claims, self.fused = False, 0, False
+        self.armed, self.claims, self.fused, self.masked = False, 0, False, False
 
 
 def arm_bwdstat(t) -> None:
@@ -431,10 +431,20 @@ def _dgrad_with_bnstats(prod, final: bool, dtype) -> bool:
             and prod.act in (L.ACT_NONE, L.ACT_LRELU) and not _os.environ.get("VG_NO_BNSTAT_FUSION"))
 
 
+def _masked_bn_bwd() -> bool:
+    """Residual BatchNorm backward on the masked gradient dz (written by the pass that takes the sums): the apply pass
+    reads two tensors and writes one instead of three and two.  VG_NO_MASKED_BN_BWD=1 restores the old passes (A/B)."""
+    return not _os.environ.get("VG_NO_MASKED_BN_BWD")
+
+
 def _bn_bwd_stats_struct(prod, sums):
     vec = prod.vec
+    # a residual BatchNorm (mask read from y): the fused launch stores the masked gradient, which is then also the skip
+    # gradient of the block (BNActFn.backward)
+    mask_out = int(prod.y is not None and prod.act == L.ACT_LRELU and _masked_bn_bwd())
     return L.BnBwdStats(x=prod.x.data_ptr(), y=L.ptr(prod.y), mean=vec[0].data_ptr(), invstd=vec[1].data_ptr(),
-                        scale=vec[2].data_ptr(), shift=vec[3].data_ptr(), sums=sums.data_ptr(), cpad=prod.cpad, act=prod.act)
+                        scale=vec[2].data_ptr(), shift=vec[3].data_ptr(), sums=sums.data_ptr(), cpad=prod.cpad, act=prod.act,
+                        mask_out=mask_out)
 
 
 def _bias_done(link) -> bool:
@@ -554,7 +564,7 @@ class Conv2dFn(torch.autograd.Function):
                                                                  int(parked is not None), C.byref(bs), C.byref(fused), L.stream()),
                                _shape_tag("dgrad", d)), "conv_dgrad_bnstats")
                 if fused.value:
-                    prod.sums, prod.fused = sums, True
+                    prod.sums, prod.fused, prod.masked = sums, True, bool(bs.mask_out)
             else:
                 L.check(_timed(None, _conv_flops(d),
                                lambda: lib.vg_conv_dgrad(C.byref(d), gy.data_ptr(), wpt.data_ptr(), None, dx.data_ptr(), None,
@@ -623,7 +633,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
                                                                C.byref(bs), C.byref(fused), L.stream()),
                                _shape_tag("convT_dgrad", d)), "convT_dgrad_bnstats")
                 if fused.value:
-                    prod.sums, prod.fused = sums, True
+                    prod.sums, prod.fused, prod.masked = sums, True, bool(bs.mask_out)
             else:
                 L.check(_timed(None, _conv_flops(d),
                                lambda: lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx.data_ptr(), None,
@@ -721,20 +731,34 @@ class BNActFn(torch.autograd.Function):
         # without a residual the LeakyReLU mask is recomputed from x (one tensor read less per pass)
         yp = None if (not ctx.has_res and ctx.act in (L.ACT_NONE, L.ACT_LRELU)) else y.data_ptr()
         bsl = ctx.bslink
+        act, dres, dres_out = ctx.act, None, None
         if bsl is not None and bsl.fused:       # the consumer's input-gradient launch already took the sums (BwdStatLink)
             sums = bsl.sums
+            if bsl.masked:                      # ... and stored the masked gradient: gy is dz, and the skip gradient
+                act, yp = L.ACT_NONE, None
+                dres = gy if ctx.has_res else None
         else:
             sums = _zeros_f64(L.STATS_REPLICAS * 2 * cpad + 2 * cpad, x.device)
-            L.check(lib.vg_bn_bwd_reduce(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
-                                         vec[2].data_ptr(), vec[3].data_ptr(), sums.data_ptr(), rows, cs, c, cpad, ctx.act, dtc,
-                                         L.stream()), "bn_bwd_reduce")
+            if ctx.has_res and ctx.act == L.ACT_LRELU and _masked_bn_bwd():
+                # the reduction writes dz = gy * mask (the skip gradient); the apply pass then reads (dz, x) only
+                dres = torch.empty_like(x)
+                L.check(lib.vg_bn_bwd_reduce_dz(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
+                                                vec[2].data_ptr(), vec[3].data_ptr(), sums.data_ptr(), dres.data_ptr(), rows,
+                                                cs, c, cpad, ctx.act, dtc, L.stream()), "bn_bwd_reduce_dz")
+                gy, act, yp = dres, L.ACT_NONE, None
+            else:
+                L.check(lib.vg_bn_bwd_reduce(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
+                                             vec[2].data_ptr(), vec[3].data_ptr(), sums.data_ptr(), rows, cs, c, cpad, ctx.act, dtc,
+                                             L.stream()), "bn_bwd_reduce")
         if bsl is not None:
             bsl.x = bsl.y = bsl.vec = bsl.sums = None
+            bsl.fused = bsl.masked = False
         sync = ctx.sync
         if sync is not None:
             sync.sum_(sums[:L.STATS_REPLICAS * 2 * cpad])
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_res else None
+        if ctx.has_res and dres is None:
+            dres = dres_out = torch.empty_like(x)
         gslot, bslot = _grad_slot(ctx.gparam), _grad_slot(ctx.bparam)
         direct = gslot is not None and bslot is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
         dgb = (gslot, bslot) if direct else torch.empty(2, c, dtype=torch.float32, device=x.device)
@@ -743,9 +767,9 @@ class BNActFn(torch.autograd.Function):
         cbslot = _grad_slot(link.bias) if (link is not None and link.bias is not None and link.bias.requires_grad) else None
         L.check(lib.vg_bn_bwd_apply(gy.data_ptr(), yp, x.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
                                     vec[2].data_ptr(), vec[3].data_ptr(), gamma.data_ptr(), sums.data_ptr(), dx.data_ptr(),
-                                    L.ptr(dres), dgb[0].data_ptr(),
+                                    L.ptr(dres_out), dgb[0].data_ptr(),
                                     dgb[1].data_ptr(), int(direct), L.ptr(cbslot), rows, ctx.count,
-                                    1.0 if sync is None else 1.0 / sync.world, cs, c, cpad, ctx.act, dtc,
+                                    1.0 if sync is None else 1.0 / sync.world, cs, c, cpad, act, dtc,
                                     L.stream()), "bn_bwd_apply")
         if cbslot is not None:
             link.done = True
