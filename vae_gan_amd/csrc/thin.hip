@@ -350,6 +350,104 @@ __global__ __launch_bounds__(256) void thin_out_kernel(const ThinParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// wide -> thin, 3x3 stride 1, without the P image: the taps of a kernel ROW go into the M dimension of a 16x16x32 MFMA.
+//   D_hy[(r,c)][px] = sum_{s,n} Wl[(r,s,c)][n] * halo[hy][px + s][n]        A = weights (12 real rows of 16), B = 16 pixels
+//   out[y][px][c]   = D_y[(0,c)][px] + D_{y+1}[(1,c)][px] + D_{y+2}[(2,c)][px]
+// One MFMA of a halo row serves the three output rows it touches; the accumulator of halo row hy holds its r = 0, 1, 2 parts
+// in lanes 0-15, 16-31, 32-47 (register index = c), so an output row is three accumulators met by two 16-lane shifts, and
+// lanes 0-15 then hold whole 8-byte output pixels.  Block = 4 waves over an 8 x 32 output tile (halo 10 x 34 pixels x 64
+// channels, 144-byte pixel stride: conflict-free 16-byte fragment reads); wave = (16-pixel strip, 4-row half): 36 MFMAs per
+// tile, weights in 24 registers.  Persistent blocks, three per CU; the next tile's halo is requested into registers before
+// this one is computed.  (The GEMM + col2im kernel above spent three barriers and a 29 KB f32 round trip through LDS per
+// 4 x 32 tile: 248 us per launch at 64 x 256 x 256, against ~105 us for its one pass over the 64-channel tensor.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void thin_out3_kernel(const ThinParams p) {
+  constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, M = IH * IW, PXB = 144, NLD = (M * 8 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];      // [M][PXB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kg = lane >> 4;
+  const int strip = wave & 1, half = wave >> 1;
+  const int tpi = p.tilesX * p.tilesY;
+  u32x4 wa[3][2];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      wa[s][kc] = u32x4{0u, 0u, 0u, 0u};
+      if (l16 < 12) wa[s][kc] = *(const u32x4*)(p.wpk + (((l16 >> 2) * 3 + s) * 4 + (l16 & 3)) * 72 + kc * 32 + kg * 8);
+    }
+  float bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bv[c] = (p.bias != nullptr && c < p.nt) ? p.bias[c] : 0.f;
+  u32x2* __restrict__ og = (u32x2*)p.out;
+
+  u32x4 nxt[NLD];
+  auto request = [&](int tile) {
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int iy0 = (trem / p.tilesX) * TH - p.pad, ix0 = (trem % p.tilesX) * TW - p.pad;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 256 * u;
+      const int q = idx >> 3, pc = idx & 7;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < M) {
+        const int hy = q / IW, hx = q - hy * IW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if ((unsigned)iy < (unsigned)p.WH && (unsigned)ix < (unsigned)p.WW && pc * 8 < p.Ws)
+          v = *(const u32x4*)(p.wide + (((size_t)img * p.WH + iy) * p.WW + ix) * p.Ws + pc * 8);
+      }
+      nxt[u] = v;
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) request(tile);
+  const unsigned char* bbase = tsm + ((half * 4 * IW + strip * 16 + l16) * PXB + kg * 16);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    const int img = tile / tpi, trem = tile - img * tpi;
+    const int ty0 = (trem / p.tilesX) * TH, tx0 = (trem % p.tilesX) * TW;
+    __syncthreads();                               // the previous tile's fragments have been read
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < M * 8) *(u32x4*)(tsm + (idx >> 3) * PXB + (idx & 7) * 16) = nxt[u];
+    }
+    if (tile + (int)gridDim.x < p.ntiles) request(tile + gridDim.x);
+    __syncthreads();
+    f32x4 acc[6];
+#pragma unroll
+    for (int hr = 0; hr < 6; ++hr) {
+      acc[hr] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const u32x4 b = *(const u32x4*)(bbase + (hr * IW + s) * PXB + kc * 64);
+          acc[hr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[s][kc]), __builtin_bit_cast(bf16x8, b),
+                                                            acc[hr], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      f32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = acc[y][c] + __shfl_down(acc[y + 1][c], 16, 64) + __shfl_down(acc[y + 2][c], 32, 64);
+      const int Y = ty0 + half * 4 + y, X = tx0 + strip * 16 + lane;
+      if (lane < 16 && Y < p.TH_ && X < p.TW_) {
+        bf16x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float f = (float)(bf16_t)(v[c] + bv[c]);
+          if (p.act == VG_ACT_LRELU) f = vg_lrelu(f);
+          else if (p.act == VG_ACT_SIGMOID) f = vg_sigmoid(f);
+          if (c >= p.nt) f = 0.f;
+          o[c] = (bf16_t)f;
+        }
+        og[((size_t)img * p.TH_ + Y) * p.TW_ + X] = __builtin_bit_cast(u32x2, o);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient.  acc[n][(r,s,c)] = sum_q wide[q][n] * thin[q*ST - pad + (r,s)][c] over all pixels q of the wide
 // tensor: K = pixels.  Persistent blocks walk 8 x 32 pixel tiles; both operands are written TRANSPOSED into LDS
 // ([channel][pixel], conflict-free 2-byte writes: a lane owns one pixel) so that a fragment is 8 consecutive pixels.
@@ -490,6 +588,24 @@ extern "C" size_t vg_thin_conv_ws_bytes(void) { return 64 * 72 * sizeof(bf16_t);
 
 static int thin_out_blocks(const ThinParams& p) { return p.ntiles < 512 ? p.ntiles : 512; }      // 2 resident blocks per CU
 
+// 3x3 stride-1 wide -> thin: the row-tap kernel (thin_out3_kernel); VG_THIN_OUT_OLD=1 keeps the GEMM + col2im kernel (A/B)
+static int launch_thin_out3(ThinParams& p, hipStream_t st) {
+  static const bool old = getenv("VG_THIN_OUT_OLD") != nullptr;
+  if (old) {
+    thin_tiles(p, p.TH_, p.TW_, 4, 32);
+    int rc = thin_lds_attr(thin_out_kernel<3, 1>, thin_out_lds<3>());
+    if (rc) return rc;
+    hipLaunchKernelGGL((thin_out_kernel<3, 1>), dim3(thin_out_blocks(p)), dim3(256), thin_out_lds<3>(), st, p);
+    return VG_OK;
+  }
+  constexpr int lds = 10 * 34 * 144;
+  thin_tiles(p, p.TH_, p.TW_, 8, 32);
+  int rc = thin_lds_attr(thin_out3_kernel, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(thin_out3_kernel, dim3(p.ntiles < 768 ? p.ntiles : 768), dim3(256), lds, st, p);      // 3 resident blocks per CU
+  return VG_OK;
+}
+
 extern "C" int vg_thin_conv_fwd(const vg_conv_desc* d, const void* x, const float* w_oihw, const float* bias, void* y,
                                 double* stats, int act, void* ws, void* stream) {
   const int kind = vg_thin_conv_supported(d);
@@ -509,10 +625,8 @@ extern "C" int vg_thin_conv_fwd(const vg_conv_desc* d, const void* x, const floa
   } else {
     VG_REQUIRE(stats == nullptr, "thin_conv_fwd: statistics are only taken on the wide side");
     p.wide = (const bf16_t*)x;
-    thin_tiles(p, p.TH_, p.TW_, 4, 32);
-    int rc = thin_lds_attr(thin_out_kernel<3, 1>, thin_out_lds<3>());
+    int rc = launch_thin_out3(p, st);
     if (rc) return rc;
-    hipLaunchKernelGGL((thin_out_kernel<3, 1>), dim3(thin_out_blocks(p)), dim3(256), thin_out_lds<3>(), st, p);
   }
   VG_LAUNCH_CHECK();
   return VG_OK;
@@ -533,10 +647,8 @@ extern "C" int vg_thin_conv_dgrad(const vg_conv_desc* d, const void* dy, const f
     p.wide = (const bf16_t*)dy;
     if (d->r == 3) {
       p.wmode = 1; p.pad = d->r - 1 - d->pad;
-      thin_tiles(p, p.TH_, p.TW_, 4, 32);
-      int rc = thin_lds_attr(thin_out_kernel<3, 1>, thin_out_lds<3>());
+      int rc = launch_thin_out3(p, st);
       if (rc) return rc;
-      hipLaunchKernelGGL((thin_out_kernel<3, 1>), dim3(thin_out_blocks(p)), dim3(256), thin_out_lds<3>(), st, p);
     } else {
       p.wmode = 2; p.pad = 1;
       thin_tiles(p, p.WH, p.WW, 4, 32);          // tiles of the dy grid; each covers 8 x 64 pixels of dx
