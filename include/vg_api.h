@@ -151,6 +151,21 @@ size_t vg_thin_conv_wgrad_ws_bytes(const vg_conv_desc* d);
 int vg_thin_conv_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, int accumulate,
                        void* stream);
 
+/* ---- the PatchGAN tail: Conv2d(C, 1, 4, stride 1, padding 1), bf16 (csrc/tail.hip) -------------
+ * The last layer of every discriminator (vq_vae_gan/model.py:221, beta_vae_gans/model.py:176,
+ * hierarchical_vae_gan/model.py:330: 512 -> 1 on a 16x16 map at 256x256 inputs).  One output channel is a dot product
+ * per pixel, not a GEMM tile: forward and weight gradient run on the vector ALUs straight from the master OIHW f32
+ * weights (rounded to bf16 like the packed images); results agree with vg_conv_fwd / vg_conv_wgrad up to the f32
+ * summation order.  The weight gradient writes one partial image per wave into `ws`
+ * (vg_conv1_wgrad_ws_bytes(d) bytes) and sums them in a fixed order: bit-reproducible.  The input gradient stays on
+ * vg_conv_dgrad.  vg_conv1_supported: co == 1, 4x4, stride 1, pad 1, ci % 8 == 0, output width <= 32, ycs in 8..64. */
+int vg_conv1_supported(const vg_conv_desc* d);
+int vg_conv1_fwd(const vg_conv_desc* d, const void* x, const float* w_oihw, const float* bias, void* y, int act,
+                 void* stream);
+size_t vg_conv1_wgrad_ws_bytes(const vg_conv_desc* d);
+int vg_conv1_wgrad(const vg_conv_desc* d, const void* x, const void* dy, float* dw_oihw, void* ws, int accumulate,
+                   void* stream);
+
 /* per-channel column sum: out[c] (f32) = sum_m a[m][c], c < c_valid.  bias gradients.
  * ws: VG_STATS_REPLICAS*cs f64 of scratch.  accumulate != 0: out[c] +=. */
 int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, double* ws, int accumulate,

@@ -247,3 +247,71 @@ def test_batched_repack_matches_single_pack(gpu, dtype):
     for i, (a, b) in enumerate(zip(want, got)):
         assert torch.equal(a.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
                            b.view(torch.int16 if dtype == torch.bfloat16 else torch.int32)), (geos[i // 2], i % 2)
+
+
+@pytest.mark.parametrize("case", [(64, 16, 16, 512, 0), (2, 8, 8, 512, 0), (3, 9, 7, 64, 1), (2, 5, 33, 24, 0), (2, 6, 20, 1024, 2)],
+                         ids=lambda c: "n%d_%dx%d_ci%d_act%d" % c)
+def test_patchgan_tail_kernels_match_float64_and_gather_gemm(gpu, case):
+    """csrc/tail.hip (vg_conv1_fwd / vg_conv1_wgrad): the one-output-channel 4x4 stride-1 conv on the vector ALUs,
+    against torch float64 on the bf16-rounded operands and against vg_conv_fwd / vg_conv_wgrad (same bound as
+    test_conv_primitives); padding channels zero; the weight gradient bit-reproducible, workspace-independent, and
+    accumulate=1 adds exactly once.  Cases: the step's shape, ragged rows, the widest row (32 outputs), two channel
+    rounds (1024), fused LeakyReLU / sigmoid."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vae_gan_amd import lib as L
+    n, h, w, ci, act = case
+    dt = torch.bfloat16
+    lib = L.load()
+    d = G.make_desc(n, h, w, ci, 1, 4, 1, 1, dt)
+    assert lib.vg_conv1_supported(C.byref(d)) == 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g)
+    wt = torch.randn(1, ci, 4, 4, generator=g) / (ci * 16) ** 0.5
+    bias = torch.randn(1, generator=g)
+    xr, wr = x.to(dt).double(), wt.to(dt).double()
+    y_ref = F.conv2d(xr, wr, bias.double(), stride=1, padding=1)
+    if act == L.ACT_LRELU:
+        y_ref = F.leaky_relu(y_ref, 0.2)
+    elif act == L.ACT_SIGMOID:
+        y_ref = torch.sigmoid(y_ref)
+    gy = torch.randn(y_ref.shape, generator=g)
+    dw_ref = torch.nn.grad.conv2d_weight(xr, wr.shape, gy.to(dt).double(), stride=1, padding=1)
+    xd, wd, bd, gyd = G.nhwc(x, d.xcs, dt), wt.cuda(), bias.cuda(), G.nhwc(gy, d.ycs, dt)
+    y = torch.full((n, d.oh, d.ow, d.ycs), float("nan"), dtype=dt, device="cuda")
+    L.check(lib.vg_conv1_fwd(C.byref(d), xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), act, L.stream()), "conv1_fwd")
+    y2 = torch.empty_like(y)
+    wp = G.pack(lib, d, wd, 0, dt)
+    L.check(lib.vg_conv_fwd(C.byref(d), xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y2.data_ptr(), None, act, 0, L.stream()), "fwd")
+    torch.cuda.synchronize()
+    assert G.rel(G.from_nhwc(y, 1), y_ref) <= 6e-3
+    assert float(y[..., 1:].float().abs().max()) == 0.0
+    assert G.rel(y[..., 0].float(), y2[..., 0].float()) <= 6e-3
+    ws = torch.empty(lib.vg_conv1_wgrad_ws_bytes(C.byref(d)) // 4, dtype=torch.float32, device="cuda")
+    outs = []
+    for _ in range(2):
+        dw = torch.full((1, ci, 4, 4), float("nan"), dtype=torch.float32, device="cuda")
+        ws.fill_(float("nan"))
+        L.check(lib.vg_conv1_wgrad(C.byref(d), xd.data_ptr(), gyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, L.stream()), "conv1_wgrad")
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert G.rel(outs[0].cpu(), dw_ref) <= 5e-3
+    assert torch.equal(outs[0], outs[1])
+    acc = outs[0].clone()
+    L.check(lib.vg_conv1_wgrad(C.byref(d), xd.data_ptr(), gyd.data_ptr(), acc.data_ptr(), ws.data_ptr(), 1, L.stream()), "conv1_wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(acc, outs[0] * 2)
+
+
+def test_patchgan_tail_rejects_other_shapes(gpu):
+    import ctypes as C
+    from vae_gan_amd import lib as L
+    lib = L.load()
+    for n, h, w, ci, co, k, s, p, dt in [(2, 8, 8, 512, 2, 4, 1, 1, torch.bfloat16), (2, 8, 8, 512, 1, 3, 1, 1, torch.bfloat16),
+                                         (2, 8, 8, 512, 1, 4, 2, 1, torch.bfloat16), (2, 8, 40, 512, 1, 4, 1, 1, torch.bfloat16),
+                                         (2, 8, 8, 512, 1, 4, 1, 1, torch.float32)]:
+        d = G.make_desc(n, h, w, ci, co, k, s, p, dt)
+        assert lib.vg_conv1_supported(C.byref(d)) == 0
+    d = G.make_desc(2, 8, 8, 512, 2, 4, 1, 1, torch.bfloat16)
+    t = torch.zeros(16, device="cuda")
+    assert lib.vg_conv1_fwd(C.byref(d), t.data_ptr(), t.data_ptr(), None, t.data_ptr(), 0, L.stream()) != 0

@@ -72,6 +72,10 @@ SIGNATURES = {
     "vg_thin_conv_dgrad": (_I, [_DP, _P, _P, _P, _P, _P]),
     "vg_thin_conv_wgrad_ws_bytes": (C.c_size_t, [_DP]),
     "vg_thin_conv_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
+    "vg_conv1_supported": (_I, [_DP]),
+    "vg_conv1_fwd": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
+    "vg_conv1_wgrad_ws_bytes": (C.c_size_t, [_DP]),
+    "vg_conv1_wgrad": (_I, [_DP, _P, _P, _P, _P, _I, _P]),
     "vg_linear_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "vg_linear_dgrad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "vg_set_deterministic": (None, [_I]),

@@ -376,6 +376,23 @@ def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape, param=No
     return None if slot is not None else dw
 
 
+def _conv1_enabled() -> bool:
+    """VG_NO_CONV1=1 sends the PatchGAN tail back to the gather-GEMM kernels (A/B)."""
+    return not _os.environ.get("VG_NO_CONV1")
+
+
+def _wgrad1(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape, param=None) -> Optional[torch.Tensor]:
+    """Weight gradient of the one-output-channel 4x4 conv (csrc/tail.hip); same contract as ``_wgrad``."""
+    lib = L.load()
+    ws = torch.empty(lib.vg_conv1_wgrad_ws_bytes(C.byref(desc)) // 4, dtype=torch.float32, device=x.device)
+    slot = _grad_slot(param)
+    dw = slot if slot is not None else torch.empty(wshape, dtype=torch.float32, device=x.device)
+    L.check(_timed("conv1", _conv_flops(desc),
+                   lambda: lib.vg_conv1_wgrad(C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(),
+                                              int(slot is not None), L.stream()), _shape_tag("wgrad", desc)), "conv1_wgrad")
+    return None if slot is not None else dw
+
+
 class BiasLink:
     """Ties a conv to the BatchNorm that consumes its raw output.  The conv's bias gradient is the per-channel sum
     of the BatchNorm input gradient; ``vg_bn_bwd_apply`` takes that sum while it writes dx, straight into the bias
@@ -492,6 +509,14 @@ class Conv2dFn(torch.autograd.Function):
                            lambda: lib.vg_thin_conv_fwd(C.byref(d), x.data_ptr(), w32.data_ptr(), L.ptr(bias), y.data_ptr(),
                                                         L.ptr(stats), act, tws.data_ptr(), L.stream()), _shape_tag("fwd", d)),
                     "thin_conv_fwd")
+        elif (co == 1 and not want_stats and dt == torch.bfloat16 and _conv1_enabled()
+              and lib.vg_conv1_supported(C.byref(d))):
+            # the PatchGAN tail (512 -> 1, 4x4 on 16x16): a dot product per pixel on the vector ALUs (csrc/tail.hip)
+            kind = 3
+            w32 = weight.detach().contiguous()
+            L.check(_timed("conv1", _conv_flops(d),
+                           lambda: lib.vg_conv1_fwd(C.byref(d), x.data_ptr(), w32.data_ptr(), L.ptr(bias), y.data_ptr(), act,
+                                                    L.stream()), _shape_tag("fwd", d)), "conv1_fwd")
         elif (co <= 32 and not want_stats and dt == torch.bfloat16 and not deterministic()
               and n * d.oh * d.ow <= 32768 and k * k * xcs >= 2048):
             # few output tiles, a long reduction (the PatchGAN tail, 512 -> 1 4x4 on 16x16: 57 tiles of 256 K steps):
@@ -525,7 +550,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.act != L.ACT_NONE:
             gy = _act_bwd(gy, y, ctx.act)
         dx = dw = db = None
-        if ctx.kind:            # thin layer: both gradients straight from the master weights
+        if ctx.kind in (1, 2):  # thin layer: both gradients straight from the master weights
             w32 = weight.detach().contiguous()
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
@@ -571,7 +596,7 @@ class Conv2dFn(torch.autograd.Function):
                                                          L.ACT_NONE, int(parked is not None), L.stream()),
                                _shape_tag("dgrad", d)), "conv_dgrad")
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(d, x, gy, weight.shape, ctx.wparam)
+            dw = (_wgrad1 if ctx.kind == 3 else _wgrad)(d, x, gy, weight.shape, ctx.wparam)
         if ctx.has_bias and ctx.needs_input_grad[2] and not _bias_done(ctx.link):
             db = _channel_sum(gy, d.co, ctx.bparam)
         if dx is not None and ctx.thin_in_cs:      # the input arrived in the thin layout: hand its gradient back the same way
