@@ -187,6 +187,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         d_loss, g_loss, _ = vq_train_step(model, images, opt_g, opt_d, dp)
+    host_dt = time.perf_counter() - t0      # all launches of the timed steps enqueued (the GPU is still working)
     barrier()
     dt = time.perf_counter() - t0
     ops.PROFILE[0] = None
@@ -234,6 +235,8 @@ def main():
             "step_tflops_necessary": imgs_per_s * gf_img / 1e3 / world if gf_img else None,
             "step_frac_of_bf16_peak": imgs_per_s * gf_img / 1e3 / world / PEAK_BF16_TFLOPS if gf_img else None,
             "losses_finite": finite,
+            # host time to enqueue a step (rank 0): the margin before the step becomes launch-bound on a slower host
+            "host_enqueue_ms_per_step": 1000.0 * host_dt / args.steps,
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline and args.arch == "vq":
