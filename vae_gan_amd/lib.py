@@ -152,7 +152,14 @@ def check(rc: int, what: str = "") -> None:
         raise RuntimeError(f"libvg_hip {what} failed (rc={rc}): {last_error()}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """hipStream_t of torch's current stream on the current device (every launch asks: the raw accessor costs
+    ~0.5 us against ~9 us for torch.cuda.current_stream(), 1.7 ms of host time per VQ step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
