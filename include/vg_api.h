@@ -244,6 +244,16 @@ int vg_add_inplace(void* a, const void* b, int64_t n, int dtype, void* stream);
  * register-resident search kernel is used (same arithmetic and indices, several times faster on large codebooks). */
 int vg_vq_assign(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx, float* norms_ws,
                  void* stream);
+/* The same indices as vg_vq_assign, bit for bit, for large codebooks (vq_vae_gan/model.py:88-95 at num_embeddings =
+ * 8192, embedding_dim = 256: BASELINE configs[4]): approximate distances on the bf16 MFMA with a rigorous error bound
+ * pick the candidates of every row (twice the cheap product: first the bound on the row's minimum, then the codes
+ * within the bound of it), the candidates' distances are then taken with the exact-f32 instruction sequence of
+ * vg_vq_assign, smallest distance, then smallest index.  A row with more than 32 candidates (or none) makes the call
+ * redo the whole search with the exact kernel (still the same result; *fallback_flag_out, a device int, optional,
+ * receives 1 then, else 0).  d in {64, 128, 256}; ws: vg_vq_shortlist_ws_bytes(rows, k, d) bytes, 256-byte aligned. */
+size_t vg_vq_shortlist_ws_bytes(int64_t rows, int k, int d);
+int vg_vq_assign_shortlist(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx, void* ws,
+                           int* fallback_flag_out, void* stream);
 /* zq = z + (E[idx] - z); sse += sum (E[idx]-z)^2 (f64 scalar, zeroed by caller); optional EMA
  * statistics counts[k] (f32) and esum[k][d] (f32), zeroed by caller (model.py:98-119). */
 int vg_vq_gather(const float* z, const float* codebook, const int64_t* idx, int64_t rows, int k, int d, float* zq,

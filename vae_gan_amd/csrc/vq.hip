@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restr
 template <int D>
 __global__ __launch_bounds__(256, 2) void vq_assign2_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                          const float* __restrict__ e2, int64_t rows, int K,
-                                                         int64_t* __restrict__ idx) {
+                                                         int64_t* __restrict__ idx, const int* __restrict__ guard) {
   constexpr int HD = D / 2, LDW = HD + 4, NV = D / 32;     // NV: f32x4 staging loads per thread per tile
+  if (guard != nullptr && *guard == 0) return;             // fallback launch of the shortlist search: nothing to redo
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* se = sm;                              // [2][32][2][LDW]
   float* sb = sm + 2 * 32 * 2 * LDW;           // [2][32]
@@ -187,7 +188,8 @@ static int launch_vq_assign2(const float* z, const float* cb, float* e2, int64_t
   VG_HIP(vg_lds_attr((const void*)vq_assign2_kernel<D>, (int)lds));
   hipLaunchKernelGGL(vq_code_norms_kernel, dim3((unsigned)vg_ceil_div(k, 256)), dim3(256), 0, st, cb, k, D, e2);
   VG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(vq_assign2_kernel<D>, dim3((unsigned)vg_ceil_div(rows, 128)), dim3(256), lds, st, z, cb, (const float*)e2, rows, k, idx);
+  hipLaunchKernelGGL(vq_assign2_kernel<D>, dim3((unsigned)vg_ceil_div(rows, 128)), dim3(256), lds, st, z, cb, (const float*)e2, rows, k, idx,
+                     (const int*)nullptr);
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -213,6 +215,309 @@ extern "C" int vg_vq_assign(const float* z, const float* codebook, int64_t rows,
     hipLaunchKernelGGL(vq_assign_kernel<2>, dim3(blocks), dim3(128), lds, st, z, codebook, rows, k, d, idx);
   }
   VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shortlist search for large codebooks (K = 8192, D = 256: the exact-f32 MFMA search above is 275 GFLOP on a 157 TF/s
+// pipe, 2.6 ms).  The SAME indices, bit for bit, from three steps:
+//  1. approximate distances on the bf16 MFMA (16x the rate): dq = |E_k|^2 - 2 zb.eb with z and E rounded to bf16.  For
+//     every (row, code) the exact kernel's f32 distance d satisfies |dq + |z|^2 - d| <= B_k with
+//       B_k = C1 |z| |E_k| + C2 (|z|^2 + |E_k|^2),   C1 = 1.02 * 2^-7,  C2 = 1.5 * 2^-22
+//     (bf16 rounding of both operands: 2 * (2^-8 + 2^-18) |z||E_k| by Cauchy-Schwarz; f32 accumulation of either
+//     kernel: D * 2^-24 |z||E_k| each, twice for the factor 2; the roundings of |z|^2 + |E_k|^2, of d, of dq and of the
+//     bound arithmetic: (1 + 2 + 1 + 1) * 2^-24 (|z|^2 + |E_k|^2), using 2 |z||E_k| <= |z|^2 + |E_k|^2; the rest of
+//     the 2 % and of the 1.5 is slack for the f32 norms and the bound's own arithmetic).  With latents of order one and a freshly initialised
+//     codebook (codes ~ 1/K) the f32 distances themselves are only a few ulp(|z|^2) apart, so a row keeps 2-3
+//     candidates on average and up to ~20: the list holds VQS_CAP = 32.  (The bound is taken per code, not per tile of
+//     codes: once the EMA has moved some codes to the latents' scale, a tile-wide bound made every small code that
+//     shares a tile with a large one a candidate.)
+//     pass 1: U = min_k (dq_k + B_k) per row: an upper bound of (exact minimum - |z|^2).
+//     pass 2 (the same product again: it is cheap): every code with dq_k - B_k <= U is a candidate.  The exact argmin
+//     k* always is: dq_k* - B_k* <= d_k* - |z|^2 <= d_j - |z|^2 <= dq_j + B_j for every j.  So is every code that ties.
+//  2. the candidates' distances on the exact-f32 MFMA, the same instruction sequence as vq_assign2 (a wave takes 32
+//     rows: A row m = candidate s of row m, B column m = z row m, the diagonal of the 32x32 tile is what is wanted),
+//     smallest distance, then smallest index.  Rows with one candidate skip this.
+//  3. a row with no candidate or more than VQS_CAP (32) sets a flag; vq_assign2 is launched after it and returns at once
+//     unless the flag is set (then it redoes the whole search: correct always, fast when the bound is not hit).
+// ---------------------------------------------------------------------------------------------
+constexpr int VQS_CAP = 32;
+#define VQS_C1 (1.02f / 128.f)
+#define VQS_C2 (1.5f / 4194304.f)
+
+// one block per tile of 32 codes: bf16 image of the codes (zero rows beyond K) and |E_k| (rounded up)
+__global__ __launch_bounds__(256) void vq_short_prep_kernel(const float* __restrict__ cb, const float* __restrict__ e2, int K, int D,
+                                                            bf16_t* __restrict__ eb, float* __restrict__ en) {
+  const int t = blockIdx.x, tid = threadIdx.x;
+  for (int q = tid; q < 32 * D / 4; q += 256) {
+    const int r = q / (D / 4), c4 = q - r * (D / 4);
+    const int code = t * 32 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (code < K) v = *(const f32x4*)(cb + (size_t)code * D + c4 * 4);
+    *(bf16x4*)(eb + (size_t)code * D + c4 * 4) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  }
+  if (tid < 32) {
+    const int code = t * 32 + tid;
+    en[code] = code < K ? sqrtf(e2[code]) * 1.000001f : 0.f;            // en has ntiles * 32 entries
+  }
+}
+
+template <int D, int J, int PASS>
+__global__ __launch_bounds__(256, 2) void vq_short_kernel(const float* __restrict__ z, const bf16_t* __restrict__ eb,
+                                                          const float* __restrict__ e2, const float* __restrict__ en,
+                                                          int64_t rows, int K, float* __restrict__ U, int* __restrict__ cnt,
+                                                          int* __restrict__ cand) {
+  constexpr int NS = D / 16;             // MFMA k steps
+  constexpr int STR = D * 2 + 16;        // LDS row stride (bytes): 16-byte fragment reads of 32 rows spread over the banks
+  constexpr int NV = D / 64;             // 16-byte staging loads per thread per tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smq[];
+  unsigned char* st = smq;                         // [2][32][STR]
+  float* sb = (float*)(smq + 2 * 32 * STR);        // [2][2][32] |E_k|^2 (1 +- C2) (+inf beyond K), |E_k|
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l32 = lane & 31;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * (32 * J) + l32;
+
+  bf16x8 zf[J][NS];
+  float cz[J], c2zz[J], ub[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int64_t row = row0 + 32 * j;
+    const float* zp = z + (size_t)(row < rows ? row : rows - 1) * D + 8 * h;
+    float n2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const f32x4 a = *(const f32x4*)(zp + 16 * s), b = *(const f32x4*)(zp + 16 * s + 4);
+      zf[j][s] = bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+      n2 += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    }
+    n2 += __shfl_xor(n2, 32, 64);
+    cz[j] = VQS_C1 * sqrtf(n2);
+    c2zz[j] = VQS_C2 * n2;
+    ub[j] = PASS == 1 ? __builtin_inff() : U[row < rows ? row : rows - 1] + c2zz[j];      // U holds min + C2 |z|^2
+  }
+  const int ntiles = (K + 31) / 32;
+  u32x4 pre[NV];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = i * 256 + tid, r = q / (D / 8), pc = q % (D / 8);
+      pre[i] = *(const u32x4*)(eb + ((size_t)tile * 32 + r) * D + pc * 8);       // eb has ntiles * 32 rows
+    }
+  };
+  auto put = [&](int tile, int buf) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = i * 256 + tid, r = q / (D / 8), pc = q % (D / 8);
+      *(u32x4*)(st + (buf * 32 + r) * STR + pc * 16) = pre[i];
+    }
+    if (tid < 32) sb[buf * 64 + tid] = tile * 32 + tid < K ? e2[tile * 32 + tid] * (PASS == 1 ? 1.f + VQS_C2 : 1.f - VQS_C2) : __builtin_inff();
+    else if (tid < 64) sb[buf * 64 + tid] = en[tile * 32 + tid - 32];
+  };
+  fetch(0);
+  put(0, 0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) fetch(t + 1);
+    f32x16 acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const unsigned char* base = st + (buf * 32 + l32) * STR + 16 * h;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const bf16x8 a = *(const bf16x8*)(base + 32 * s);
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zf[j][s], acc[j], 0, 0, 0);
+    }
+    if (t + 1 < ntiles) put(t + 1, buf ^ 1);
+    // dq_k +- B_k = (|E_k|^2 (1 +- C2) +- C1 |z| |E_k|) - 2 zb.eb +- C2 |z|^2: two FMAs per element, the row term apart
+    float e2r[16], enr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cl = (r & 3) + 8 * (r >> 2) + 4 * h;
+      e2r[r] = sb[buf * 64 + cl];
+      enr[r] = sb[buf * 64 + 32 + cl];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (PASS == 1) {
+        float m = ub[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fminf(m, __builtin_fmaf(-2.f, acc[j][r], __builtin_fmaf(cz[j], enr[r], e2r[r])));
+        ub[j] = m;
+      } else {
+        unsigned hit = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          hit |= (__builtin_fmaf(-2.f, acc[j][r], __builtin_fmaf(-cz[j], enr[r], e2r[r])) <= ub[j]) ? 1u << r : 0u;
+        const int64_t row = row0 + 32 * j;
+        if (hit != 0 && row < rows) {
+          while (hit) {
+            const int r = __builtin_ctz(hit);
+            hit &= hit - 1;
+            const int code = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int pos = atomicAdd(&cnt[row], 1);
+            if (pos < VQS_CAP) cand[(size_t)row * VQS_CAP + pos] = code;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (PASS == 1) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const float u = fminf(ub[j], __shfl_xor(ub[j], 32, 64)) + c2zz[j];
+      const int64_t row = row0 + 32 * j;
+      if (h == 0 && row < rows) U[row] = u;
+    }
+  }
+}
+
+// exact distances of the candidates: the arithmetic of vq_assign2 (same |z|^2 loop, same MFMA chain in k order, same
+// distance expression), so the same bits
+template <int D>
+__global__ __launch_bounds__(256) void vq_short_exact_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                             const float* __restrict__ e2, int64_t rows, int K,
+                                                             const int* __restrict__ cnt, const int* __restrict__ cand,
+                                                             int64_t* __restrict__ idx, int* __restrict__ flag) {
+  constexpr int HD = D / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, l32 = lane & 31;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 32 + l32;
+  const int64_t rc = row < rows ? row : rows - 1;
+  int n = cnt[rc];
+  if ((n < 1 || n > VQS_CAP) && row < rows && h == 0) atomicOr(flag, 1);
+  n = n < 1 ? 1 : (n > VQS_CAP ? VQS_CAP : n);
+  int nmax = n;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  const int* cr = cand + (size_t)rc * VQS_CAP;
+  if (nmax == 1) {                                            // wave-uniform: every row of the wave has its answer
+    if (h == 0 && row < rows) idx[row] = min(max(cr[0], 0), K - 1);
+    return;
+  }
+  float zr[HD];
+  float zz = 0.f;
+  {
+    const float* zp = z + (size_t)rc * D;
+#pragma unroll
+    for (int c4 = 0; c4 < D / 4; ++c4) {
+      const f32x4 v = *(const f32x4*)(zp + c4 * 4);
+      zz += v[0] * v[0]; zz += v[1] * v[1]; zz += v[2] * v[2]; zz += v[3] * v[3];
+      zr[2 * c4] = h ? v[1] : v[0];
+      zr[2 * c4 + 1] = h ? v[3] : v[2];
+      if (c4 % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int hsel = (l32 >> 2) & 1, rsel = (l32 & 3) + 4 * (l32 >> 3);      // where the diagonal element of column l32 sits
+  float best = __builtin_inff();
+  int besti = 0x7fffffff;
+  for (int s = 0; s < nmax; ++s) {
+    int code = cr[s < n ? s : n - 1];
+    code = min(max(code, 0), K - 1);
+    const float* ep = cb + (size_t)code * D;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < D / 4; ++c4) {
+      const f32x4 v = *(const f32x4*)(ep + c4 * 4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[1] : v[0], zr[2 * c4], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[3] : v[2], zr[2 * c4 + 1], acc, 0, 0, 0);
+      if (c4 % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    float dv = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) dv = rsel == r ? acc[r] : dv;
+    const float ov = __shfl_xor(dv, 32, 64);
+    const float sd = h == hsel ? dv : ov;
+    const float dist = (zz + e2[code]) - 2.f * sd;
+    if (dist < best || (dist == best && code < besti)) { best = dist; besti = code; }
+  }
+  if (h == 0 && row < rows) idx[row] = besti;
+}
+
+struct VqShortWs {
+  float *e2, *en, *U;
+  int *cnt, *flag, *cand;
+  bf16_t* eb;
+  size_t bytes;
+};
+static VqShortWs vq_short_layout(void* ws, int64_t rows, int k, int d) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t ntiles = (size_t)(k + 31) / 32;
+  unsigned char* b = (unsigned char*)ws;
+  VqShortWs w;
+  size_t o = 0;
+  w.e2 = (float*)(b + o); o += up((size_t)k * 4);
+  w.en = (float*)(b + o); o += up(ntiles * 32 * 4);
+  w.U = (float*)(b + o); o += up((size_t)rows * 4);
+  w.cnt = (int*)(b + o); o += up((size_t)rows * 4);          // cnt and flag are cleared by one memset
+  w.flag = (int*)(b + o); o += 256;
+  w.cand = (int*)(b + o); o += up((size_t)rows * VQS_CAP * 4);
+  w.eb = (bf16_t*)(b + o); o += up(ntiles * 32 * (size_t)d * 2);
+  w.bytes = o;
+  return w;
+}
+
+extern "C" size_t vg_vq_shortlist_ws_bytes(int64_t rows, int k, int d) {
+  if (rows <= 0 || k <= 0 || (d != 64 && d != 128 && d != 256)) return 0;
+  return vq_short_layout(nullptr, rows, k, d).bytes;
+}
+
+template <int D>
+static int launch_vq_short(const float* z, const float* cb, int64_t rows, int k, int64_t* idx, const VqShortWs& w, hipStream_t st) {
+  const int ntiles = (k + 31) / 32;
+  constexpr size_t lds = (size_t)2 * 32 * (D * 2 + 16) + 512;
+  hipLaunchKernelGGL(vq_code_norms_kernel, dim3((unsigned)vg_ceil_div(k, 256)), dim3(256), 0, st, cb, k, D, w.e2);
+  hipLaunchKernelGGL(vq_short_prep_kernel, dim3(ntiles), dim3(256), 0, st, cb, (const float*)w.e2, k, D, w.eb, w.en);
+  VG_HIP(hipMemsetAsync(w.cnt, 0, (size_t)((unsigned char*)w.flag - (unsigned char*)w.cnt) + 256, st));
+  // two row sets per wave (each fragment read feeds two MFMAs) once that still gives every CU two blocks; at D = 256
+  // the second set of z fragments does not fit the register file
+  bool two = false;
+  if constexpr (D <= 128) two = rows >= 2 * 256 * 256;
+  if constexpr (D <= 128) if (two) {
+    const unsigned blocks = (unsigned)vg_ceil_div(rows, 256);
+    hipLaunchKernelGGL((vq_short_kernel<D, 2, 1>), dim3(blocks), dim3(256), lds, st, z, (const bf16_t*)w.eb, (const float*)w.e2,
+                       (const float*)w.en, rows, k, w.U, w.cnt, w.cand);
+    hipLaunchKernelGGL((vq_short_kernel<D, 2, 2>), dim3(blocks), dim3(256), lds, st, z, (const bf16_t*)w.eb, (const float*)w.e2,
+                       (const float*)w.en, rows, k, w.U, w.cnt, w.cand);
+  }
+  if (!two) {
+    const unsigned blocks = (unsigned)vg_ceil_div(rows, 128);
+    hipLaunchKernelGGL((vq_short_kernel<D, 1, 1>), dim3(blocks), dim3(256), lds, st, z, (const bf16_t*)w.eb, (const float*)w.e2,
+                       (const float*)w.en, rows, k, w.U, w.cnt, w.cand);
+    hipLaunchKernelGGL((vq_short_kernel<D, 1, 2>), dim3(blocks), dim3(256), lds, st, z, (const bf16_t*)w.eb, (const float*)w.e2,
+                       (const float*)w.en, rows, k, w.U, w.cnt, w.cand);
+  }
+  VG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vq_short_exact_kernel<D>, dim3((unsigned)vg_ceil_div(rows, 128)), dim3(256), 0, st, z, cb, (const float*)w.e2, rows, k,
+                     (const int*)w.cnt, (const int*)w.cand, idx, w.flag);
+  VG_LAUNCH_CHECK();
+  constexpr size_t lds2 = (size_t)(2 * 32 * 2 * (D / 2 + 4) + 64) * sizeof(float);
+  VG_HIP(vg_lds_attr((const void*)vq_assign2_kernel<D>, (int)lds2));
+  hipLaunchKernelGGL(vq_assign2_kernel<D>, dim3((unsigned)vg_ceil_div(rows, 128)), dim3(256), lds2, st, z, cb, (const float*)w.e2, rows, k, idx,
+                     (const int*)w.flag);
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+
+extern "C" int vg_vq_assign_shortlist(const float* z, const float* codebook, int64_t rows, int k, int d, int64_t* idx, void* ws,
+                                      int* fallback_flag_out, void* stream) {
+  VG_REQUIRE(z && codebook && idx && ws && rows > 0 && k > 0, "vq_assign_shortlist: bad arguments");
+  VG_REQUIRE(d == 64 || d == 128 || d == 256, "vq_assign_shortlist: embedding_dim %d unsupported (64, 128 or 256)", d);
+  VG_REQUIRE(((uintptr_t)ws & 255) == 0, "vq_assign_shortlist: the workspace must be 256-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const VqShortWs w = vq_short_layout(ws, rows, k, d);
+  int rc;
+  if (d == 64) rc = launch_vq_short<64>(z, codebook, rows, k, idx, w, st);
+  else if (d == 128) rc = launch_vq_short<128>(z, codebook, rows, k, idx, w, st);
+  else rc = launch_vq_short<256>(z, codebook, rows, k, idx, w, st);
+  if (rc) return rc;
+  if (fallback_flag_out != nullptr) VG_HIP(hipMemcpyAsync(fallback_flag_out, w.flag, sizeof(int), hipMemcpyDeviceToDevice, st));
   return VG_OK;
 }
 

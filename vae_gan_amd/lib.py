@@ -94,6 +94,8 @@ SIGNATURES = {
     "vg_act_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P]),
     "vg_add_inplace": (_I, [_P, _P, _L, _I, _P]),
     "vg_vq_assign": (_I, [_P, _P, _L, _I, _I, _P, _P, _P]),
+    "vg_vq_shortlist_ws_bytes": (C.c_size_t, [_L, _I, _I]),
+    "vg_vq_assign_shortlist": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "vg_vq_gather": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "vg_vq_ema_update": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
     "vg_vq_bwd": (_I, [_P, _P, _P, _P, _L, _F, _P, _P]),

@@ -875,6 +875,9 @@ class AddFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------
 # vector quantiser
 # ----------------------------------------------------------------------------------------------
+VQ_SHORTLIST_MIN_K = 2048     # below this the exact-f32 search is tens of microseconds
+
+
 class VectorQuantizeFn(torch.autograd.Function):
     """vq_vae_gan/model.py:68-134 on NCHW f32 input: indices, straight-through output, VQ loss and the
     in-place EMA codebook update (when ``training``)."""
@@ -891,9 +894,15 @@ class VectorQuantizeFn(torch.autograd.Function):
         flat = torch.empty(rows, d, dtype=torch.float32, device=dev)
         L.check(lib.vg_nchw_to_nhwc(z.data_ptr(), flat.data_ptr(), b, d, h, w, d, L.VG_F32, L.stream()), "vq.flatten")
         idx = torch.empty(rows, dtype=torch.int64, device=dev)
-        norms = torch.empty(k, dtype=torch.float32, device=dev)
-        L.check(lib.vg_vq_assign(flat.data_ptr(), codebook.data_ptr(), rows, k, d, idx.data_ptr(), norms.data_ptr(),
-                                 L.stream()), "vq_assign")
+        if k >= VQ_SHORTLIST_MIN_K and d in (64, 128, 256) and not _os.environ.get("VG_NO_VQ_SHORTLIST"):
+            # large codebooks: candidates from the bf16 MFMA, exact-f32 distances for those only (same indices)
+            ws = torch.empty(lib.vg_vq_shortlist_ws_bytes(rows, k, d), dtype=torch.uint8, device=dev)
+            L.check(lib.vg_vq_assign_shortlist(flat.data_ptr(), codebook.data_ptr(), rows, k, d, idx.data_ptr(), ws.data_ptr(),
+                                               None, L.stream()), "vq_assign_shortlist")
+        else:
+            norms = torch.empty(k, dtype=torch.float32, device=dev)
+            L.check(lib.vg_vq_assign(flat.data_ptr(), codebook.data_ptr(), rows, k, d, idx.data_ptr(), norms.data_ptr(),
+                                     L.stream()), "vq_assign")
         zq_flat = torch.empty_like(flat)
         scal = _zeros_f64(2, dev)       # [sse, unused]
         counts = esum = None
