@@ -90,6 +90,15 @@ __global__ __launch_bounds__(NW * 64) void vq_assign_kernel(const float* __restr
 //  * the next tile's global loads are issued before the MFMA loop and land in LDS after it,
 // which leaves 67 KB of LDS per 4-wave block: two blocks per CU, two waves on every SIMD.
 // ---------------------------------------------------------------------------------------------
+// |z|^2 in k order, one fused multiply-add per element: spelled out so that every kernel that needs the exact search's
+// |z|^2 gets the same bits (left to the compiler, `zz += v * v` was contracted in one kernel and not in another)
+__device__ __forceinline__ float vq_sq4(float zz, const f32x4 v) {
+  zz = __builtin_fmaf(v[0], v[0], zz);
+  zz = __builtin_fmaf(v[1], v[1], zz);
+  zz = __builtin_fmaf(v[2], v[2], zz);
+  return __builtin_fmaf(v[3], v[3], zz);
+}
+
 __global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restrict__ cb, int K, int D, float* __restrict__ e2) {
   const int code = blockIdx.x * 256 + threadIdx.x;
   if (code >= K) return;
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void vq_assign2_kernel(const float* __restr
 #pragma unroll
     for (int c4 = 0; c4 < D / 4; ++c4) {
       const f32x4 v = *(const f32x4*)(zp + c4 * 4);
-      zz += v[0] * v[0]; zz += v[1] * v[1]; zz += v[2] * v[2]; zz += v[3] * v[3];
+      zz = vq_sq4(zz, v);
       zr[2 * c4] = h ? v[1] : v[0];
       zr[2 * c4 + 1] = h ? v[3] : v[2];
       if (c4 % 8 == 7) __builtin_amdgcn_sched_barrier(0);      // keep at most 8 row loads in flight (register pressure)
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void vq_short_kernel(const float* __restric
       const f32x4 a = *(const f32x4*)(zp + 16 * s), b = *(const f32x4*)(zp + 16 * s + 4);
       zf[j][s] = bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
       n2 += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+      if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // eight row loads in flight, not all of them (registers)
     }
     n2 += __shfl_xor(n2, 32, 64);
     cz[j] = VQS_C1 * sqrtf(n2);
@@ -330,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void vq_short_kernel(const float* __restric
       const bf16x8 a = *(const bf16x8*)(base + 32 * s);
 #pragma unroll
       for (int j = 0; j < J; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, zf[j][s], acc[j], 0, 0, 0);
+      if (J * D >= 512 && (s & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // at most four fragment reads hoisted ahead
     }
     if (t + 1 < ntiles) put(t + 1, buf ^ 1);
     // dq_k +- B_k = (|E_k|^2 (1 +- C2) +- C1 |z| |E_k|) - 2 zb.eb +- C2 |z|^2: two FMAs per element, the row term apart
@@ -377,67 +388,86 @@ __global__ __launch_bounds__(256, 2) void vq_short_kernel(const float* __restric
 }
 
 // exact distances of the candidates: the arithmetic of vq_assign2 (same |z|^2 loop, same MFMA chain in k order, same
-// distance expression), so the same bits
+// distance expression), so the same bits.  A wave takes 32 rows and walks their (row, candidate) PAIRS 32 at a time
+// (rows keep 2-3 candidates on average but up to 32: a slot-per-round walk ran as many rounds as the longest list):
+// lane m of a round holds pair p = 32 * round + m, A row m = its code, B column m = its z row, and the diagonal of the
+// 32x32 tile is the pair's product.  The distances go to LDS; each row then picks among its own.
 template <int D>
 __global__ __launch_bounds__(256) void vq_short_exact_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                              const float* __restrict__ e2, int64_t rows, int K,
                                                              const int* __restrict__ cnt, const int* __restrict__ cand,
                                                              int64_t* __restrict__ idx, int* __restrict__ flag) {
-  constexpr int HD = D / 2;
+  __shared__ int spre[4][32];
+  __shared__ float sdist[4][32 * VQS_CAP];
+  __shared__ int scode[4][32 * VQS_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, l32 = lane & 31;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 32 + l32;
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int64_t row = base + l32;
   const int64_t rc = row < rows ? row : rows - 1;
   int n = cnt[rc];
   if ((n < 1 || n > VQS_CAP) && row < rows && h == 0) atomicOr(flag, 1);
   n = n < 1 ? 1 : (n > VQS_CAP ? VQS_CAP : n);
-  int nmax = n;
+  int incl = n;
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-  const int* cr = cand + (size_t)rc * VQS_CAP;
-  if (nmax == 1) {                                            // wave-uniform: every row of the wave has its answer
-    if (h == 0 && row < rows) idx[row] = min(max(cr[0], 0), K - 1);
+  for (int o = 1; o < 32; o <<= 1) {
+    const int t = __shfl_up(incl, o, 32);
+    if (l32 >= o) incl += t;
+  }
+  const int excl = incl - n;
+  const int P = __shfl(incl, 31, 32);                          // pairs of the wave's 32 rows (the same in both halves)
+  if (P == 32) {                                               // wave-uniform: one candidate per row, nothing to compare
+    if (h == 0 && row < rows) idx[row] = min(max(cand[(size_t)rc * VQS_CAP], 0), K - 1);
     return;
   }
-  float zr[HD];
-  float zz = 0.f;
-  {
-    const float* zp = z + (size_t)rc * D;
+  if (h == 0) spre[wave][l32] = excl;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int hsel = (l32 >> 2) & 1, rsel = (l32 & 3) + 4 * (l32 >> 3);      // where the diagonal element of column l32 sits
+  for (int p0 = 0; p0 < P; p0 += 32) {
+    const int p = p0 + l32 < P ? p0 + l32 : P - 1;
+    int r = 0;
+#pragma unroll
+    for (int st = 16; st > 0; st >>= 1)
+      if (spre[wave][r + st] <= p) r += st;                    // r + st <= 31
+    const int64_t prow = base + r < rows ? base + r : rows - 1;
+    int code = cand[(size_t)prow * VQS_CAP + (p - spre[wave][r])];
+    code = min(max(code, 0), K - 1);
+    const float* zp = z + (size_t)prow * D;
+    const float* ep = cb + (size_t)code * D;
+    float zz = 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
     for (int c4 = 0; c4 < D / 4; ++c4) {
       const f32x4 v = *(const f32x4*)(zp + c4 * 4);
-      zz += v[0] * v[0]; zz += v[1] * v[1]; zz += v[2] * v[2]; zz += v[3] * v[3];
-      zr[2 * c4] = h ? v[1] : v[0];
-      zr[2 * c4 + 1] = h ? v[3] : v[2];
-      if (c4 % 8 == 7) __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  const int hsel = (l32 >> 2) & 1, rsel = (l32 & 3) + 4 * (l32 >> 3);      // where the diagonal element of column l32 sits
-  float best = __builtin_inff();
-  int besti = 0x7fffffff;
-  for (int s = 0; s < nmax; ++s) {
-    int code = cr[s < n ? s : n - 1];
-    code = min(max(code, 0), K - 1);
-    const float* ep = cb + (size_t)code * D;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int c4 = 0; c4 < D / 4; ++c4) {
-      const f32x4 v = *(const f32x4*)(ep + c4 * 4);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[1] : v[0], zr[2 * c4], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[3] : v[2], zr[2 * c4 + 1], acc, 0, 0, 0);
+      const f32x4 e = *(const f32x4*)(ep + c4 * 4);
+      zz = vq_sq4(zz, v);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? e[1] : e[0], h ? v[1] : v[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? e[3] : e[2], h ? v[3] : v[2], acc, 0, 0, 0);
       if (c4 % 8 == 7) __builtin_amdgcn_sched_barrier(0);
     }
     float dv = acc[0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) dv = rsel == r ? acc[r] : dv;
+    for (int q = 1; q < 16; ++q) dv = rsel == q ? acc[q] : dv;
     const float ov = __shfl_xor(dv, 32, 64);
     const float sd = h == hsel ? dv : ov;
     const float dist = (zz + e2[code]) - 2.f * sd;
-    if (dist < best || (dist == best && code < besti)) { best = dist; besti = code; }
+    if (h == 0 && p0 + l32 < P) { sdist[wave][p] = dist; scode[wave][p] = code; }
   }
-  if (h == 0 && row < rows) idx[row] = besti;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (h == 0 && row < rows) {
+    float best = __builtin_inff();
+    int besti = 0x7fffffff;
+    for (int q = excl; q < excl + n; ++q) {
+      const float dist = sdist[wave][q];
+      const int code = scode[wave][q];
+      if (dist < best || (dist == best && code < besti)) { best = dist; besti = code; }
+    }
+    idx[row] = besti == 0x7fffffff ? 0 : besti;
+  }
 }
 
 struct VqShortWs {
