@@ -533,22 +533,35 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p) {
 }
 
 // dW[o][i][r][s] (+)= sum over the partial images, fixed order.  wmode 0: acc[n = o][(r,s,c = i)]; 1: acc[n = i][(R-1-r, R-1-s, c = o)]
-__global__ __launch_bounds__(64) void thin_wgrad_finish_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw,
-                                                               int O, int I, int R, int wmode, int accumulate) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= O * I * R * R) return;
-  const int s = t % R, r = (t / R) % R, i = (t / (R * R)) % I, o = t / (R * R * I);
-  const int idx = wmode == 0 ? o * 64 + (r * 4 + s) * 4 + i : i * 64 + ((R - 1 - r) * 4 + (R - 1 - s)) * 4 + o;
+// A block takes 16 outputs; its 16 thread groups split the partial images (group g: g, g + 16, ...; eight loads in
+// flight), LDS combines the groups in order: a few memory latencies per launch instead of nparts / 8 in a chain.
+__global__ __launch_bounds__(256) void thin_wgrad_finish_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dw,
+                                                                int O, int I, int R, int wmode, int accumulate) {
+  __shared__ float red[16][16];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int t = blockIdx.x * 16 + e;
+  const bool ok = t < O * I * R * R;
   float v = 0.f;
-  int b = 0;
-  for (; b + 8 <= nparts; b += 8) {
-    float a[8];
+  if (ok) {
+    const int s = t % R, r = (t / R) % R, i = (t / (R * R)) % I, o = t / (R * R * I);
+    const int idx = wmode == 0 ? o * 64 + (r * 4 + s) * 4 + i : i * 64 + ((R - 1 - r) * 4 + (R - 1 - s)) * 4 + o;
+    int b = g;
+    for (; b + 7 * 16 < nparts; b += 8 * 16) {
+      float a[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = part[(size_t)(b + u) * 4096 + idx];
-    v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      for (int u = 0; u < 8; ++u) a[u] = part[(size_t)(b + 16 * u) * 4096 + idx];
+      v += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    for (; b < nparts; b += 16) v += part[(size_t)b * 4096 + idx];
   }
-  for (; b < nparts; ++b) v += part[(size_t)b * 4096 + idx];
-  dw[t] = accumulate ? dw[t] + v : v;
+  red[g][e] = v;
+  __syncthreads();
+  if (g == 0 && ok) {
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum += red[q][e];
+    dw[t] = accumulate ? dw[t] + sum : sum;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -702,7 +715,7 @@ extern "C" int vg_thin_conv_wgrad(const vg_conv_desc* d, const void* x, const vo
   }
   VG_LAUNCH_CHECK();
   const int total = d->co * d->ci * d->r * d->r;
-  hipLaunchKernelGGL(thin_wgrad_finish_kernel, dim3((total + 63) / 64), dim3(64), 0, st, (const float*)ws, blocks, dw_oihw,
+  hipLaunchKernelGGL(thin_wgrad_finish_kernel, dim3((total + 15) / 16), dim3(256), 0, st, (const float*)ws, blocks, dw_oihw,
                      d->co, d->ci, d->r, p.wmode, accumulate);
   VG_LAUNCH_CHECK();
   return VG_OK;
