@@ -1000,6 +1000,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         const size_t off = ok ? (size_t)pix * p.Ks + n : 0;
         xr[rd].v = *(const decltype(xr[rd].v)*)((const T*)p.bs.x + off);
         if (p.bs.y != nullptr) yr[rd].v = *(const decltype(yr[rd].v)*)((const T*)p.bs.y + off);
+        else yr[rd].v = xr[rd].v;      // never looked at
       }
     }
     if (fast) {
@@ -1068,18 +1069,34 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         for (int e = 0; e < PIECE; ++e) o.set(e, o.get(e) + old.get(e));
       }
       if (bs) {        // o = the gradient as stored (what the BatchNorm backward will read)
-        const float* cf = coef + wn * WN_COLS + pc * PIECE;
+        // Straight-line code: the lane's four coefficient pieces come in with eight 16-byte LDS reads up front and the
+        // launch-uniform choices (mask source, activation, mask_out) are selects.  Written with a branch per choice and
+        // element, the compiler read every coefficient pair right where it was used, behind a uniform branch, and waited
+        // for it: eight LDS latencies in a chain per store round, which is what the fused sums cost (not their VALU work).
+        const f32x4* cf4 = (const f32x4*)(coef + wn * WN_COLS + pc * PIECE);
+        float c0[PIECE], c1[PIECE], c2[PIECE], c3[PIECE];
+#pragma unroll
+        for (int q4 = 0; q4 < PIECE / 4; ++q4) {
+          const f32x4 t0 = cf4[q4], t1 = cf4[BN / 4 + q4], t2 = cf4[2 * BN / 4 + q4], t3 = cf4[3 * BN / 4 + q4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { c0[4 * q4 + k] = t0[k]; c1[4 * q4 + k] = t1[k]; c2[4 * q4 + k] = t2[k]; c3[4 * q4 + k] = t3[k]; }
+        }
         const bool mask_out = p.bs.mask_out != 0;       // store dz (the masked gradient) instead of dout
+        const bool use_y = p.bs.y != nullptr;
+        const float slope = p.bs.act == VG_ACT_LRELU ? VG_LRELU_SLOPE : 1.f;
+        Piece<T> om = o;
 #pragma unroll
         for (int e = 0; e < PIECE; ++e) {
           const float xf = xr[rd].get(e);
-          float dz = o.get(e);
-          const float pre = p.bs.y != nullptr ? yr[rd].get(e) : xf * cf[e] + cf[BN + e];
-          if (p.bs.act == VG_ACT_LRELU && !(pre > 0.f)) dz *= VG_LRELU_SLOPE;
-          if (mask_out) { o.set(e, dz); dz = o.get(e); }    // the sums are those of the value as stored
+          const float prex = xf * c0[e] + c1[e];
+          const float pre = use_y ? yr[rd].get(e) : prex;
+          const float dzm = o.get(e) * (pre > 0.f ? 1.f : slope);
+          om.set(e, dzm);
+          const float dz = mask_out ? om.get(e) : dzm;    // the sums are those of the value as stored
           bs1[e] += dz;
-          bs2[e] += dz * (xf * cf[2 * BN + e] - cf[3 * BN + e]);
+          bs2[e] += dz * (xf * c2[e] - c3[e]);
         }
+        if (mask_out) o = om;
       }
       *(decltype(o.v)*)dst = o.v;
     }

@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
 //   wide_out = 0 (thin_out_kernel): row (r*R+s)*4+c, column n:     wmode 0: W[c][n][r][s]; 1: W[n][c][R-1-r][R-1-s]; 2: W[n][c][r][s]
 __global__ __launch_bounds__(256) void thin_pack_kernel(const ThinParams p, bf16_t* __restrict__ wpk, int wide_out) {
   const int R = p.R;
-  for (int idx = threadIdx.x; idx < 64 * 72; idx += 256) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 64 * 72; idx += gridDim.x * 256) {      // one element per thread
     const int row = idx / 72, col = idx - row * 72;
     float v = 0.f;
     if (col < 64) {
@@ -628,7 +628,7 @@ extern "C" int vg_thin_conv_fwd(const vg_conv_desc* d, const void* x, const floa
   ThinParams p;
   thin_fill(d, kind, p);
   p.w = w_oihw; p.bias = bias; p.act = act; p.wmode = 0; p.pad = d->pad; p.out = (bf16_t*)y; p.wpk = (const bf16_t*)ws;
-  hipLaunchKernelGGL(thin_pack_kernel, dim3(1), dim3(256), 0, st, p, (bf16_t*)ws, kind == 1 ? 1 : 0);
+  hipLaunchKernelGGL(thin_pack_kernel, dim3(64 * 72 / 256), dim3(256), 0, st, p, (bf16_t*)ws, kind == 1 ? 1 : 0);
   VG_LAUNCH_CHECK();
   if (kind == 1) {
     p.thin = (const bf16_t*)x; p.stats = stats; p.cpad = d->co <= 32 ? 32 : 64; p.det = vg_det_mode();
@@ -654,7 +654,7 @@ extern "C" int vg_thin_conv_dgrad(const vg_conv_desc* d, const void* dy, const f
   thin_fill(d, kind, p);
   p.w = w_oihw; p.act = VG_ACT_NONE; p.out = (bf16_t*)dx; p.wpk = (const bf16_t*)ws;
   p.wmode = kind == 2 ? 1 : (d->r == 3 ? 1 : 2);
-  hipLaunchKernelGGL(thin_pack_kernel, dim3(1), dim3(256), 0, st, p, (bf16_t*)ws, kind == 2 ? 1 : 0);
+  hipLaunchKernelGGL(thin_pack_kernel, dim3(64 * 72 / 256), dim3(256), 0, st, p, (bf16_t*)ws, kind == 2 ? 1 : 0);
   VG_LAUNCH_CHECK();
   if (kind == 1) {          // dx thin <- dy wide
     p.wide = (const bf16_t*)dy;
