@@ -4,6 +4,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import vae_gan_amd.lib as L
+if os.environ.get("VG_LIB_EXP"):      # A/B against another build: libvg_hip_<tag>.so
+    _v = os.environ["VG_LIB_EXP"]
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), f"libvg_hip_{'exp' if _v == '1' else _v}.so")
 
 lib = L.load()
 dev = "cuda"

@@ -67,11 +67,15 @@ __device__ __forceinline__ void load_coef(const float* __restrict__ a, int ch0, 
 // ---------------------------------------------------------------------------------------------
 // Thread (rr, pc) owns one 16-byte channel piece `pc` for the rows rr, rr+rpb*grid, ...: its PIECE
 // scale/shift coefficients stay in registers, and a wave still touches 1 KiB of contiguous memory.
-template <typename T, bool HAS_RES>
+// ACT >= 0: the activation is a compile-time constant (LeakyReLU: every BatchNorm of the training step); ACT < 0: the
+// run-time argument decides.  With the run-time test alone the compiler kept four scalar branches PER ELEMENT in the
+// unrolled loops (the sigmoid's division sequence behind one of them): instruction issue, not memory, paced the pass.
+template <typename T, bool HAS_RES, int ACT>
 __global__ __launch_bounds__(256, 4) void bn_act_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int64_t rows, int ppr, int c, int act) {
+                                                         int64_t rows, int ppr, int c, int act_rt) {
   constexpr int PIECE = Elt<T>::PIECE;
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int rpb = 256 / ppr;
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
   if (rr >= rpb) return;
@@ -143,13 +147,16 @@ extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const floa
   int nb_fwd = row_blocks(rows, 256 / ppr, 16);
   if (nb_fwd > 4096) nb_fwd = 4096;
   dim3 g(nb_fwd), b(256);
-  if (dtype == VG_BF16) {
-    if (res) hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, scale, shift, np, ppr, c, act);
-    else hipLaunchKernelGGL((bn_act_fwd_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (bf16_t*)y, scale, shift, np, ppr, c, act);
-  } else {
-    if (res) hipLaunchKernelGGL((bn_act_fwd_kernel<float, true>), g, b, 0, st, (const float*)x, (const float*)res, (float*)y, scale, shift, np, ppr, c, act);
-    else hipLaunchKernelGGL((bn_act_fwd_kernel<float, false>), g, b, 0, st, (const float*)x, (const float*)nullptr, (float*)y, scale, shift, np, ppr, c, act);
-  }
+#define VG_BN_FWD(T, R, A)                                                                                                  \
+  hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, A>), g, b, 0, st, (const T*)x, (const T*)res, (T*)y, scale, shift, np, ppr, c, act)
+#define VG_BN_FWD_T(T)                                                                                                       \
+  do {                                                                                                                       \
+    if (act == VG_ACT_LRELU) { if (res) VG_BN_FWD(T, true, VG_ACT_LRELU); else VG_BN_FWD(T, false, VG_ACT_LRELU); }          \
+    else { if (res) VG_BN_FWD(T, true, -1); else VG_BN_FWD(T, false, -1); }                                                  \
+  } while (0)
+  if (dtype == VG_BF16) VG_BN_FWD_T(bf16_t); else VG_BN_FWD_T(float);
+#undef VG_BN_FWD_T
+#undef VG_BN_FWD
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -165,14 +172,15 @@ extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const floa
 // WRITE_DZ: the masked gradient dz = dout * act'(.) is also written out (dzout may be dout itself: every element is read
 // and written by the same thread), and the sums are those of the value as stored.  The apply pass then needs neither y nor
 // the mask, and a residual BatchNorm's skip gradient IS that tensor (see vg_bn_bwd_reduce_dz).
-template <typename T, bool XMASK, bool WRITE_DZ = false>
+template <typename T, bool XMASK, bool WRITE_DZ, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* __restrict__ y,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, double* __restrict__ sums,
-                                                            int64_t rows, int cs, int c, int cpad, int act, int det,
-                                                            T* dzout = nullptr) {
+                                                            int64_t rows, int cs, int c, int cpad, int act_rt, int det,
+                                                            T* dzout) {
   constexpr int PIECE = Elt<T>::PIECE;
+  const int act = ACT >= 0 ? ACT : act_rt;       // see bn_act_fwd_kernel
   __shared__ float red[256 * PIECE * 2];
   const int ppr = cs / PIECE;                        // pieces per row (<= 256 guaranteed by launcher)
   const int rpb = 256 / ppr;                         // rows handled per block pass
@@ -270,23 +278,20 @@ static int bn_bwd_reduce_launch(const void* dout, const void* y, const void* x, 
   if (y == nullptr && !xmask) y = x;    // no activation: the value is never looked at
   const int det = vg_det_mode();
   dim3 g((unsigned)blocks), b(256);
-  if (dz != nullptr) {
-#define VG_BN_REDUCE_DZ(T, XM)                                                                                           \
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, XM, true>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
+#define VG_BN_REDUCE(T, XM, DZ, A)                                                                                            \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, XM, DZ, A>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
                      scale, shift, sums, rows, cs, c, cpad, act, det, (T*)dz)
-    if (dtype == VG_BF16) { if (xmask) VG_BN_REDUCE_DZ(bf16_t, true); else VG_BN_REDUCE_DZ(bf16_t, false); }
-    else { if (xmask) VG_BN_REDUCE_DZ(float, true); else VG_BN_REDUCE_DZ(float, false); }
-#undef VG_BN_REDUCE_DZ
-    VG_LAUNCH_CHECK();
-    return VG_OK;
-  }
-  if (dtype == VG_BF16) {
-    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, false>), g, b, 0, st, (const bf16_t*)dout, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
-  } else {
-    if (xmask) hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), g, b, 0, st, (const float*)dout, (const float*)y, (const float*)x, mean, invstd, scale, shift, sums, rows, cs, c, cpad, act, det);
-  }
+#define VG_BN_REDUCE_A(T, XM, DZ)                                                                                             \
+  do { if (act == VG_ACT_LRELU) VG_BN_REDUCE(T, XM, DZ, VG_ACT_LRELU); else VG_BN_REDUCE(T, XM, DZ, -1); } while (0)
+#define VG_BN_REDUCE_T(T)                                                                                                     \
+  do {                                                                                                                        \
+    if (dz != nullptr) { if (xmask) VG_BN_REDUCE_A(T, true, true); else VG_BN_REDUCE_A(T, false, true); }                     \
+    else { if (xmask) VG_BN_REDUCE_A(T, true, false); else VG_BN_REDUCE_A(T, false, false); }                                 \
+  } while (0)
+  if (dtype == VG_BF16) VG_BN_REDUCE_T(bf16_t); else VG_BN_REDUCE_T(float);
+#undef VG_BN_REDUCE_T
+#undef VG_BN_REDUCE_A
+#undef VG_BN_REDUCE
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
@@ -333,15 +338,16 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int c, int c
   if (dxsum) dxsum[ch] = dxs0 + (float)((double)a * (s1 - count * (double)m1));
 }
 
-template <typename T, bool HAS_DRES, bool XMASK>
+template <typename T, bool HAS_DRES, bool XMASK, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                            const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, const float* __restrict__ coef,
                                                            T* __restrict__ dx, T* __restrict__ dres,
                                                            float* __restrict__ dxsum, int64_t rows,
-                                                           int ppr, int c, int cpad, int act) {
+                                                           int ppr, int c, int cpad, int act_rt) {
   constexpr int PIECE = Elt<T>::PIECE;
+  const int act = ACT >= 0 ? ACT : act_rt;       // see bn_act_fwd_kernel
   __shared__ float red[256 * PIECE];
   const int rpb = 256 / ppr;
   const int pc = threadIdx.x % ppr, rr = threadIdx.x / ppr;
@@ -447,16 +453,19 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
     if (nblocks > cap) nblocks = cap;
   }
   dim3 g(nblocks), b(256);
-#define VG_BN_APPLY(T, DR, XM)                                                                                      \
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DR, XM>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
+#define VG_BN_APPLY(T, DR, XM, A)                                                                                   \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, DR, XM, A>), g, b, 0, st, (const T*)dout, (const T*)y, (const T*)x, mean, invstd, \
                      scale, shift, coef, (T*)dx, (T*)dres, dxsum, np, ppr, c, cpad, act)
-  if (dtype == VG_BF16) {
-    if (dres) { if (xmask) VG_BN_APPLY(bf16_t, true, true); else VG_BN_APPLY(bf16_t, true, false); }
-    else { if (xmask) VG_BN_APPLY(bf16_t, false, true); else VG_BN_APPLY(bf16_t, false, false); }
-  } else {
-    if (dres) { if (xmask) VG_BN_APPLY(float, true, true); else VG_BN_APPLY(float, true, false); }
-    else { if (xmask) VG_BN_APPLY(float, false, true); else VG_BN_APPLY(float, false, false); }
-  }
+#define VG_BN_APPLY_A(T, DR, XM)                                                                                    \
+  do { if (act == VG_ACT_LRELU) VG_BN_APPLY(T, DR, XM, VG_ACT_LRELU); else VG_BN_APPLY(T, DR, XM, -1); } while (0)
+#define VG_BN_APPLY_T(T)                                                                                            \
+  do {                                                                                                              \
+    if (dres) { if (xmask) VG_BN_APPLY_A(T, true, true); else VG_BN_APPLY_A(T, true, false); }                      \
+    else { if (xmask) VG_BN_APPLY_A(T, false, true); else VG_BN_APPLY_A(T, false, false); }                         \
+  } while (0)
+  if (dtype == VG_BF16) VG_BN_APPLY_T(bf16_t); else VG_BN_APPLY_T(float);
+#undef VG_BN_APPLY_T
+#undef VG_BN_APPLY_A
 #undef VG_BN_APPLY
   VG_LAUNCH_CHECK();
   return VG_OK;
