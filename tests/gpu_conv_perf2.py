@@ -4,7 +4,8 @@ import os
 import torch
 from vae_gan_amd import lib as L
 if os.environ.get("VG_LIB_EXP"):
-    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libvg_hip_exp.so")
+    _v = os.environ["VG_LIB_EXP"]
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), f"libvg_hip_{'exp' if _v == '1' else _v}.so")
 from gpu_conv_perf import bench
 from gpu_ops_check import make_desc
 

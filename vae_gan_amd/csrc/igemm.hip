@@ -981,6 +981,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
     __syncthreads();
   }
   constexpr int ROUNDS = 32 * PPR / 64;          // store rounds of one 32-row block: 16-byte piece lane + 64*rd
+  static_assert(64 % PPR == 0, "a lane keeps its piece column over the store rounds");
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const unsigned* rp = rowpix + (wm * MI + (flip ? MI - 1 - i : i)) * 32;    // see the A window of the main loop
@@ -1052,6 +1053,34 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (fast && !bs) {
+      // whole tile, no fused sums (forward launches, plain input gradients): everything the block's store rounds read is
+      // requested before the first round uses it - pixel indices and staged pieces (LDS), old values of a += launch
+      // (memory) - instead of two LDS latencies in a chain (and a memory latency with +=) per round.  With the fused sums
+      // the extra live registers spill and cost more than the waits.
+      unsigned pixr[ROUNDS];
+      Piece<T> stg[ROUNDS];
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int q = lane + 64 * rd;
+        const int lrow = q / PPR, pc = q - lrow * PPR;
+        pixr[rd] = rp[lrow];
+        stg[rd].v = *(const decltype(stg[rd].v)*)(wt + lrow * WN_COLS + pc * PIECE);
+      }
+      const int ncol = n0 + wn * WN_COLS + (lane % PPR) * PIECE;      // 64 % PPR == 0: the same piece column in every round
+      if (p.accumulate) {
+        Piece<T> oldr[ROUNDS];
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) oldr[rd].v = *(const decltype(oldr[rd].v)*)(yg + (size_t)pixr[rd] * p.Ks + ncol);
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+#pragma unroll
+          for (int e = 0; e < PIECE; ++e) stg[rd].set(e, stg[rd].get(e) + oldr[rd].get(e));
+        }
+      }
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) *(decltype(stg[rd].v)*)(yg + (size_t)pixr[rd] * p.Ks + ncol) = stg[rd].v;
+    } else
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
       const int q = lane + 64 * rd;
