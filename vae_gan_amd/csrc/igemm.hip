@@ -705,7 +705,11 @@ struct Igemm3Cfg {
 // that chunk is tap (2dr+a, 2ds+b) of the ordinary packed forward weights, and pieces that leave the image in one
 // plane but not in another are fetched from a block of zeros for that plane.  The activations then travel L2 -> LDS
 // once per tile instead of once per tap (16x) as in the im2col-row kernel that ran these layers at 27 % MFMA busy.
-template <typename T, int MI, int NI, int WM, int WN, int R, int S, bool S2>
+// EPI: the epilogue features an instantiation carries.  0: all of them; 1: forward (bias, activation, BatchNorm
+// statistics; plain stores); 2: plain gradient (no activation, no statistics, no fused sums; += allowed); 3: gradient with
+// the fused BatchNorm-backward sums.  The launcher picks by the launch's arguments.  One kernel with every feature behind
+// run-time tests is ~110 KB of code, most of it epilogue variants a launch never runs, and its size costs time.
+template <typename T, int MI, int NI, int WM, int WN, int R, int S, bool S2, int EPI>
 __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   typedef Igemm3Cfg<T, MI, NI, WM, WN, R, S> Cfg;
   static_assert(WM * WN == 8, "two groups of four waves");
@@ -959,11 +963,14 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
     bv[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
     a1[j] = f32x2{0.f, 0.f}; a2[j] = f32x2{0.f, 0.f};
   }
-  const bool fast = sizeof(T) == 2 && ty0 + TH <= p.OHl && tx0 + TW <= p.OWl && n0 + BN <= p.Nout && p.act != VG_ACT_SIGMOID;
-  const bool want_stats = p.stats != nullptr;
+  constexpr bool E_FWD = EPI <= 1, E_ACC = EPI != 1, E_BS = EPI == 0 || EPI == 3;
+  const int act = E_FWD ? p.act : (int)VG_ACT_NONE;
+  const bool accumulate = E_ACC && p.accumulate;
+  const bool fast = sizeof(T) == 2 && ty0 + TH <= p.OHl && tx0 + TW <= p.OWl && n0 + BN <= p.Nout && act != VG_ACT_SIGMOID;
+  const bool want_stats = E_FWD && p.stats != nullptr;
   // BatchNorm-backward sums of the tile (see IgemmParams::bs): coefficients of this block's channels go to LDS once,
   // every lane keeps the partial sums of ITS 16-byte channel piece (lane % PPR is the same in every store round)
-  const bool bs = p.bs.x != nullptr;
+  const bool bs = E_BS && p.bs.x != nullptr;
   float* coef = (float*)(smem + Cfg::COEF_OFF);       // [scale | shift | invstd | mean*invstd][BN]
   float bs1[PIECE], bs2[PIECE];
 #pragma unroll
@@ -1031,7 +1038,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       if constexpr (sizeof(T) == 2) {
         typedef std::integral_constant<bool, true> Yes;
         typedef std::integral_constant<bool, false> No;
-        if (p.act == VG_ACT_LRELU) { if (want_stats) lean(Yes{}, Yes{}); else lean(Yes{}, No{}); }
+        if (act == VG_ACT_LRELU) { if (want_stats) lean(Yes{}, Yes{}); else lean(Yes{}, No{}); }
         else { if (want_stats) lean(No{}, Yes{}); else lean(No{}, No{}); }
       }
     } else {
@@ -1044,8 +1051,8 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
           float v = acc[i][j][r] + bv[j];
           v = Elt<T>::to_f(Elt<T>::from_f(v));
           if (rp[lrow] != 0xFFFFFFFFu) { a1[j][0] += v; a2[j][0] += v * v; }
-          if (p.act == VG_ACT_LRELU) v = vg_lrelu(v);
-          else if (p.act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
+          if (act == VG_ACT_LRELU) v = vg_lrelu(v);
+          else if (act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
           if (n >= p.Nout) v = 0.f;
           wt[lrow * WN_COLS + j * 32 + l32] = Elt<T>::from_f(v);
         }
@@ -1068,7 +1075,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         stg[rd].v = *(const decltype(stg[rd].v)*)(wt + lrow * WN_COLS + pc * PIECE);
       }
       const int ncol = n0 + wn * WN_COLS + (lane % PPR) * PIECE;      // 64 % PPR == 0: the same piece column in every round
-      if (p.accumulate) {
+      if (accumulate) {
         Piece<T> oldr[ROUNDS];
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) oldr[rd].v = *(const decltype(oldr[rd].v)*)(yg + (size_t)pixr[rd] * p.Ks + ncol);
@@ -1091,7 +1098,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       Piece<T> o;
       o.v = *(const decltype(o.v)*)(wt + lrow * WN_COLS + pc * PIECE);
       T* dst = yg + (size_t)pix * p.Ks + n;
-      if (p.accumulate) {
+      if (accumulate) {
         Piece<T> old;
         old.v = *(const decltype(old.v)*)dst;
 #pragma unroll
@@ -1182,13 +1189,22 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
 }
 #undef VG_STAMP
 
-template <typename T, int MI, int NI, int WM, int WN, int R, int S>
+template <typename T, int MI, int NI, int WM, int WN, int R, int S, int EPI>
 __global__ __launch_bounds__(512) void igemm3_kernel(const IgemmParams p) {
-  igemm3_body<T, MI, NI, WM, WN, R, S, false>(p);
+  igemm3_body<T, MI, NI, WM, WN, R, S, false, EPI>(p);
 }
-template <typename T, int MI, int NI, int WM, int WN>
+template <typename T, int MI, int NI, int WM, int WN, int EPI>
 __global__ __launch_bounds__(512) void igemm3s2_kernel(const IgemmParams p) {
-  igemm3_body<T, MI, NI, WM, WN, 2, 2, true>(p);
+  igemm3_body<T, MI, NI, WM, WN, 2, 2, true, EPI>(p);
+}
+// which instantiation a launch needs (see igemm3_body)
+static int igemm3_epi(const IgemmParams& p) {
+  static const bool generic = getenv("VG_IGEMM3_GENERIC") != nullptr;      // A/B: the all-features kernel for every launch
+  if (generic) return 0;
+  const bool fwd_features = p.act != VG_ACT_NONE || p.stats != nullptr;
+  if (p.bs.x != nullptr) return fwd_features ? 0 : 3;
+  if (!fwd_features) return 2;
+  return p.accumulate ? 0 : 1;
 }
 
 template <typename T, int MI, int NI, int WM, int WN, int R, int S>
@@ -1226,11 +1242,22 @@ static int launch_igemm3(const IgemmParams& p0, hipStream_t st, bool* handled) {
     p.tilesY = (int)vg_ceil_div(p.OHl, Cfg::TH);
     p.mtiles = p.N * p.tilesX * p.tilesY;
     p.ntiles = p.Npad / Cfg::BN;
-    auto kern = igemm3_kernel<T, MI, NI, WM, WN, R, S>;
-      VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));
     pack_taps(p);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm3<%s,%d,%d,%d,%d,%dx%d>", tname<T>(), MI, NI, WM, WN, R, S);
-    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.nphases), dim3(Cfg::NT), Cfg::LDS, st, p);
+    const dim3 grid(p.mtiles * p.ntiles, p.nphases);
+#define VG_IGEMM3_LAUNCH(E)                                                                \
+  do {                                                                                     \
+    auto kern = igemm3_kernel<T, MI, NI, WM, WN, R, S, E>;                                 \
+    VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));                                    \
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS, st, p);                        \
+  } while (0)
+    switch (igemm3_epi(p)) {
+      case 1: VG_IGEMM3_LAUNCH(1); break;
+      case 2: VG_IGEMM3_LAUNCH(2); break;
+      case 3: VG_IGEMM3_LAUNCH(3); break;
+      default: VG_IGEMM3_LAUNCH(0); break;
+    }
+#undef VG_IGEMM3_LAUNCH
     VG_LAUNCH_CHECK();
     *handled = true;
   }
@@ -1259,11 +1286,17 @@ static int launch_igemm3s2(const IgemmParams& p0, hipStream_t st, bool* handled)
     p.tilesY = (int)vg_ceil_div(p.OHl, Cfg::TH);
     p.mtiles = p.N * p.tilesX * p.tilesY;
     p.ntiles = p.Npad / Cfg::BN;
-    auto kern = igemm3s2_kernel<T, MI, NI, WM, WN>;
-      VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));
     pack_taps(p);
     snprintf(g_last_kernel, sizeof g_last_kernel, "igemm3s2<%s,%d,%d,%d,%d>", tname<T>(), MI, NI, WM, WN);
-    hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, 1), dim3(Cfg::NT), Cfg::LDS, st, p);
+    const dim3 grid(p.mtiles * p.ntiles, 1);
+#define VG_IGEMM3S2_LAUNCH(E)                                                              \
+  do {                                                                                     \
+    auto kern = igemm3s2_kernel<T, MI, NI, WM, WN, E>;                                     \
+    VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));                                    \
+    hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS, st, p);                        \
+  } while (0)
+    if (igemm3_epi(p) == 1) VG_IGEMM3S2_LAUNCH(1); else VG_IGEMM3S2_LAUNCH(0);        // a forward kernel
+#undef VG_IGEMM3S2_LAUNCH
     VG_LAUNCH_CHECK();
     *handled = true;
   }
