@@ -162,17 +162,76 @@ def _ref_vq_step(model, images, opt_g, opt_d):
     return dl, gl, idx1, idx2, recon
 
 
-def _vq_step_run(dtype, iters=2):
+class _Bf16Storage:
+    """The reference with bf16 STORAGE (float64 arithmetic): what an ideal bf16 engine computes.  Every tensor the HIP
+    engine keeps in bf16 is rounded where the engine rounds it: the output of every convolution, transposed convolution,
+    LeakyReLU and Sigmoid (forward hooks; their backward rounds nothing extra, like the casts' own backward in
+    ``_unit_run``), and the conv / Linear weights the kernels read (``weights()``: the float masters are put back before
+    the optimizer steps, as the engine keeps f32 masters and re-packs bf16 images after each step)."""
+
+    def __init__(self, model):
+        self.model, self.hooks = model, []
+        for leaf in model.modules():
+            if isinstance(leaf, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.LeakyReLU, torch.nn.Sigmoid)):
+                self.hooks.append(leaf.register_forward_hook(lambda _m, _i, o: o.to(torch.bfloat16).to(o.dtype)))
+
+    def weights(self):
+        model = self.model
+
+        class _W:
+            def __enter__(w):
+                w.saved = [(p_, p_.data) for p_ in model.parameters() if p_.dim() >= 2]
+                for p_, d in w.saved:
+                    p_.data = d.to(torch.bfloat16).to(d.dtype)
+
+            def __exit__(w, *exc):
+                for p_, d in w.saved:
+                    p_.data = d
+                return False
+        return _W()
+
+    def close(self):
+        for h in self.hooks:
+            h.remove()
+
+
+def _ref_vq_step_bf16(model, images, opt_g, opt_d, st):
+    """``_ref_vq_step`` with bf16 storage (see _Bf16Storage); the optimizers step the float masters."""
+    rnd = lambda t: t.to(torch.bfloat16).to(t.dtype)
+    images = rnd(images)
+    opt_d.zero_grad()
+    with st.weights():
+        recon, _, _, vq_loss, idx1 = model(images)
+        d_real = model.discriminator(images)
+        d_fake = model.discriminator(recon.detach())
+        dl = model.loss_function(images, recon, vq_loss, d_real, d_fake, train_generator=False)
+        dl["total"].backward()
+    opt_d.step()
+    opt_g.zero_grad()
+    with st.weights():
+        recon, _, _, vq_loss, idx2 = model(images)
+        d_fake = model.discriminator(recon)
+        gl = model.loss_function(images, recon, vq_loss, d_real, d_fake, train_generator=True)
+        gl["total"].backward()
+    opt_g.step()
+    return dl, gl, idx1, idx2, recon
+
+
+def _vq_step_run(dtype, iters=2, size=64, bf16_storage=False):
     m = load_ref("vq_vae_gan", "model")
     cfg = load_ref("vq_vae_gan", "config").Config()
     model = filled(m.VQVAEGAN(cfg)).to(dtype).train()
     opt_g = torch.optim.Adam(list(model.encoder.parameters()) + list(model.decoder.parameters()),
                              lr=cfg.lr, betas=(cfg.beta1, cfg.beta2))
     opt_d = torch.optim.Adam(model.discriminator.parameters(), lr=cfg.lr / 2, betas=(cfg.beta1, cfg.beta2))
-    images = synthetic_images(2, 64, seed=42).to(dtype)
+    images = synthetic_images(2, size, seed=42).to(dtype)
     out = {"images": images.float()}
+    st = _Bf16Storage(model) if bf16_storage else None
     for it in range(iters):
-        dl, gl, idx1, idx2, recon = _ref_vq_step(model, images, opt_g, opt_d)
+        if st is not None:
+            dl, gl, idx1, idx2, recon = _ref_vq_step_bf16(model, images, opt_g, opt_d, st)
+        else:
+            dl, gl, idx1, idx2, recon = _ref_vq_step(model, images, opt_g, opt_d)
         out.update({f"it{it}_d_loss": dl["total"].item(), f"it{it}_d_recon": dl["recon"],
                     f"it{it}_g_loss": gl["total"].item(), f"it{it}_recon": gl["recon"],
                     f"it{it}_vq": gl["vq"], f"it{it}_adv": gl["adv"],
@@ -180,27 +239,42 @@ def _vq_step_run(dtype, iters=2):
     return out, model.state_dict()
 
 
-def g_vq_step():
+def g_vq_step(name="vq_step_64", iters=2, size=64):
     """Two iterations of the reference step in fp32 (the golden) and in fp64 (to record how far
     the reference's own fp32 run is from exact arithmetic: 'noise:*').  Adam's first step is
     lr*sign(g), so parameters whose gradient is rounding noise move by +-lr in a direction that
-    depends on summation order; scalars downstream are reproducible only to that floor."""
-    out, sd = _vq_step_run(torch.float32)
-    out64, _ = _vq_step_run(torch.float64)
+    depends on summation order; scalars downstream are reproducible only to that floor.
+    'noise_bf16:it0_*' = the first iteration's scalars of the reference run with bf16 STORAGE (_Bf16Storage) against
+    the fp64 run: the floor a bf16 engine has on them (the bounds of the bf16 step tests derive from it)."""
+    out, sd = _vq_step_run(torch.float32, iters, size)
+    out64, _ = _vq_step_run(torch.float64, iters, size)
+    outb, _ = _vq_step_run(torch.float64, 1, size, bf16_storage=True)
+    for k, v in outb.items():
+        if k.startswith("it0_") and not k.endswith(("idx1", "idx2", "recon_img")):
+            out["noise_bf16:" + k] = abs(v - out64[k]) / max(abs(out64[k]), 1e-12)
+            out["b:" + k] = v
+        if k == "it0_idx2":
+            out["idxeq_bf16:it0_idx2"] = float((v == out64[k]).float().mean())
     for k, v in list(out.items()):
         if k.startswith("it") and not k.endswith(("idx1", "idx2", "recon_img")):
             out["noise:" + k] = abs(v - out64[k]) / max(abs(out64[k]), 1e-12)
-        if k.endswith(("idx1", "idx2")):
+        if k.startswith("it") and k.endswith(("idx1", "idx2")):
             out["idxeq64:" + k] = float((v == out64[k]).float().mean())
-        if k.endswith("recon_img"):
+        if k.startswith("it") and k.endswith("recon_img"):
             out["noise:" + k] = rel_l2(v, out64[k])
     for k, v in sd.items():
         if v.dtype == torch.int64 or k.startswith("vector_quantizer"):
             out["sd:" + k] = v.clone()
         else:
             out["sdd:" + k] = digest(k, v)
-    save("vq_step_64", **out)
-    print({k: v for k, v in out.items() if k.startswith(("noise:", "idxeq64"))})
+    save(name, **out)
+    print({k: v for k, v in out.items() if k.startswith(("noise:", "noise_bf16:", "idxeq"))})
+
+
+def g_vq_step_256():
+    """one iteration of the reference VQ step at the reference's own image_size = 256 (B = 2):
+    the shapes at which the benchmarked kernels (igemm3, igemm3s2, igemm4, igemm4c, igemm4p, thin, wgrad3) are selected."""
+    g_vq_step("vq_step_256", iters=1, size=256)
 
 
 def g_losses():
@@ -533,7 +607,7 @@ def g_layer_units():
 
 
 GROUPS = {"layer_units": g_layer_units, "vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
-          "vq_step": g_vq_step, "losses": g_losses, "beta_modules": g_beta_modules,
+          "vq_step": g_vq_step, "vq_step_256": g_vq_step_256, "losses": g_losses, "beta_modules": g_beta_modules,
           "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step, "vq_codec": g_vq_codec, "augment": g_augment}
 
 if __name__ == "__main__":

@@ -77,6 +77,13 @@ __device__ __forceinline__ int tap_off(unsigned long long pack, int tap) { retur
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   __device__ static inline f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef VG_EXP_MMA16   // timing experiment (make exp EXTRA=-DVG_EXP_MMA16; WRONG results): the same FLOPs as two 16x16x32 MFMAs
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c1, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) { c[i] = c0[i]; c[4 + i] = c1[i]; }
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
@@ -94,6 +101,17 @@ template <> struct Mma<float> {
 __device__ __attribute__((aligned(64))) const uint32_t vg_zero_block[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 __device__ __forceinline__ int lds_off64(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
+
+// igemm3, bf16: fragments of v_mfma_f32_16x16x32_bf16 (lane = row m = lane % 16, 16-byte k slot kb = lane / 16).  For
+// that read pattern the slot is swizzled by bit 2 of the row: the four 16-lane groups a ds_read_b128 is served in then
+// hit 16 distinct 16-byte bank groups for every tap shift (rows a, a+4, a+8, a+12 of a residue class carry slots
+// kb, kb', kb', kb with kb' = kb ^ 1: the xor by 2 * (row/4 % 2) separates them).
+template <bool M16> __device__ __forceinline__ int igemm3_swz(int slot, int row) {
+  return M16 ? ((slot ^ (((row >> 2) & 1) << 1)) & 3) : ((slot ^ (row >> 2)) & 3);
+}
+__device__ __forceinline__ f32x4 mma16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   // bijective: blocks that share an XCD (bid % 8) get one contiguous range of logical ids
@@ -737,6 +755,11 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   const int group = wave >> 2;
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l32 = lane & 31;
+  // bf16: v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it than on 32x32x16 at the same cycles per FLOP:
+  // +8..16 % on these kernels).  A 32-pixel tile row = two 16-pixel A tiles (mh), 32 channels = two 16-channel B tiles (nh);
+  // lane = row / column m16 of its tile, kb = its 16-byte k slot of the 64-byte chunk.  f32: 32x32x2, lane halves as before.
+  constexpr bool M16 = sizeof(T) == 2;
+  const int m16 = lane & 15, kb = lane >> 4;
   const int lid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
   const int ntile = lid % p.ntiles, mtile = lid / p.ntiles;
   const int phase = blockIdx.y;
@@ -778,7 +801,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
           if ((unsigned)(row0 + (ab >> 1)) < (unsigned)p.H && (unsigned)(col0 + (ab & 1)) < (unsigned)p.W) m |= 1u << ab;
       }
       pval[rd] = m;
-      const long off = (((long)(img * p.H + row0) * p.W + col0) * p.Cs) * EB + (((ps ^ (hx >> 2)) & 3) << 4);
+      const long off = (((long)(img * p.H + row0) * p.W + col0) * p.Cs) * EB + (igemm3_swz<M16>(ps, hx) << 4);
       if (m) o = (unsigned)(int)off;
       poff[rd] = o;
       if (m == 0 && q * 16 < HBYTES) {
@@ -788,7 +811,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
     } else {
       pval[rd] = 0;
       if (hy < HH && hx < TW + S - 1 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        o = (unsigned)((((size_t)(img * p.H + iy) * p.W + ix) * p.Cs) * EB) + (((ps ^ (hx >> 2)) & 3) << 4);
+        o = (unsigned)((((size_t)(img * p.H + iy) * p.W + ix) * p.Cs) * EB) + (igemm3_swz<M16>(ps, hx) << 4);
       poff[rd] = o;
       if (o == 0xFFFFFFFFu && q * 16 < HBYTES) {
 #pragma unroll
@@ -810,25 +833,41 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   for (int i = 0; i < LPB; ++i) {
     const int q = i * NT + wave * BLANES + (lane & (BLANES - 1));
     const int row = q >> 2, ps = q & 3;
-    boff[i] = (unsigned)((row * ktot + (((ps ^ (row >> 2)) & 3) * PIECE)) * EB);
+    boff[i] = (unsigned)((row * ktot + (igemm3_swz<M16>(ps, row) * PIECE)) * EB);
   }
-  // fragment addresses: A = ct[s] + scalar(tile), +i*HSB per 32-row block, ^32 for the second k step;
-  // B = bfo + scalar(slot), +2048 per 32-column block, ^32 likewise
+  // fragment addresses.  f32: A = ct[s] + scalar(tile), +i*HSB per 32-row block, ^32 for the second k step;
+  // B = bfo + scalar(slot), +2048 per 32-column block, ^32 likewise.  bf16: A tile mh = +1024 (16 pixels: the swizzle bit
+  // is the same), B tile (jj, nh) = +(2*jj + nh)*1024
   int ct[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int hx = l32 + (flip ? S - 1 - s : s);
-    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4);
+    const int hx = (M16 ? m16 : l32) + (flip ? S - 1 - s : s);
+    ct[s] = hx * 64 + (igemm3_swz<M16>(M16 ? kb : h, hx) << 4);
   }
-  const int bfo = lds_off64(wn * NI * 32 + l32, h) + SB_OFF;
+  const int brow = wn * NI * 32 + (M16 ? m16 : l32);
+  const int bfo = brow * 64 + (igemm3_swz<M16>(M16 ? kb : h, brow) << 4) + SB_OFF;
 
-  f32x16 acc[MI][NI];
+  // accumulators.  f32: acc[i][j] = 32 x 32 (row (r&3) + 8*(r>>2) + 4h, column l32).  bf16: acc4[i][mh][j][nh] = 16 x 16
+  // (pixel mh*16 + 4*kb + r, column j*32 + nh*16 + m16)
+  f32x16 acc[M16 ? 1 : MI][M16 ? 1 : NI];
+  f32x4 acc4[M16 ? MI : 1][2][M16 ? NI : 1][2];
+  if constexpr (M16) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) acc4[i][mh][j][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
   // ---- DMA helpers; tap / round arguments are compile-time after unrolling
   auto dma_b = [&](int i, int itap, int icc, int slot) {
@@ -906,16 +945,30 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
 #pragma unroll
       for (int ph = 0; ph < NPH; ++ph) {
         u32x4 fb[KPP][NI];
-        // ---- memory part: fragments of this phase, DMA prefetch, retire the next tile's DMA
+        // ---- memory part: fragments of this phase, DMA prefetch, retire the next tile's DMA.
+        // f32: step j is the k half.  bf16: an MFMA takes all 32 k values, step j is the 16-COLUMN half nh of every
+        // 32-column block; the new window rows of both 16-pixel halves mh (win[mh]) are read in the K tile's first step
 #pragma unroll
         for (int kk = 0; kk < KPP; ++kk) {
           const int j = ph * KPP + kk;
-          const int va = j ? va0 ^ 32 : va0, vb = VG_DBG(4) ? 0 : (j ? vb0 ^ 32 : vb0);
+          if constexpr (M16) {
+            if (j == 0) {
 #pragma unroll
-          for (int u = (r == 0 ? 0 : r + MI - 1); u < r + MI; ++u)
-            win[j][u] = *(const u32x4*)(smem + (VG_DBG(4) ? 0 : va + u * wstep));
+              for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-          for (int jj = 0; jj < NI; ++jj) fb[kk][jj] = *(const u32x4*)(smem + vb + jj * 2048);
+                for (int u = (r == 0 ? 0 : r + MI - 1); u < r + MI; ++u)
+                  win[mh][u] = *(const u32x4*)(smem + (VG_DBG(4) ? 0 : va0 + mh * 1024 + u * wstep));
+            }
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) fb[kk][jj] = *(const u32x4*)(smem + (VG_DBG(4) ? 0 : vb0 + (2 * jj + j) * 1024));
+          } else {
+            const int va = j ? va0 ^ 32 : va0, vb = VG_DBG(4) ? 0 : (j ? vb0 ^ 32 : vb0);
+#pragma unroll
+            for (int u = (r == 0 ? 0 : r + MI - 1); u < r + MI; ++u)
+              win[j][u] = *(const u32x4*)(smem + (VG_DBG(4) ? 0 : va + u * wstep));
+#pragma unroll
+            for (int jj = 0; jj < NI; ++jj) fb[kk][jj] = *(const u32x4*)(smem + vb + jj * 2048);
+          }
         }
         if (!VG_DBG(1)) {
 #pragma unroll
@@ -932,7 +985,15 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
 #pragma unroll
           for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int jj = 0; jj < NI; ++jj) acc[i][jj] = Mma<T>::run(win[ph * KPP + kk][r + i], fb[kk][jj], acc[i][jj]);
+            for (int jj = 0; jj < NI; ++jj) {
+              if constexpr (M16) {
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+                  acc4[i][mh][jj][ph * KPP + kk] = mma16x16x32(win[mh][r + i], fb[kk][jj], acc4[i][mh][jj][ph * KPP + kk]);
+              } else {
+                acc[i][jj] = Mma<T>::run(win[ph * KPP + kk][r + i], fb[kk][jj], acc[i][jj]);
+              }
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (!VG_DBG(2)) __builtin_amdgcn_s_barrier();
@@ -955,14 +1016,21 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   T* __restrict__ yg = (T*)p.y;
-  float bv[NI];
-  f32x2 a1[NI], a2[NI];
+  // bf16 staging tile: the lanes of a 32-lane store group hold rows R and R+4 of the same 16 columns (kb and kb+1), which
+  // are the same banks in a plain [row][column] tile; all eight waves stage at once, so the conflict would double the
+  // LDS-array time of the epilogue.  Rows with bit 2 set keep their two column halves swapped.
+  auto wt_off = [&](int lrow, int col) { return lrow * WN_COLS + (M16 ? col ^ (((lrow >> 2) & 1) * (WN_COLS / 2)) : col); };
+  constexpr int NH = M16 ? 2 : 1;        // bf16: a lane holds column nh*16 + m16 of each 32-column block, f32: column l32
+  float bv[NI][NH];
+  f32x2 a1[NI][NH], a2[NI][NH];
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = n0 + (wn * NI + j) * 32 + l32;
-    bv[j] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
-    a1[j] = f32x2{0.f, 0.f}; a2[j] = f32x2{0.f, 0.f};
-  }
+  for (int j = 0; j < NI; ++j)
+#pragma unroll
+    for (int nh = 0; nh < NH; ++nh) {
+      const int n = n0 + (wn * NI + j) * 32 + (M16 ? nh * 16 + m16 : l32);
+      bv[j][nh] = (p.bias != nullptr && n < p.Nout) ? p.bias[n] : 0.f;
+      a1[j][nh] = f32x2{0.f, 0.f}; a2[j][nh] = f32x2{0.f, 0.f};
+    }
   constexpr bool E_FWD = EPI <= 1, E_ACC = EPI != 1, E_BS = EPI == 0 || EPI == 3;
   const int act = E_FWD ? p.act : (int)VG_ACT_NONE;
   const bool accumulate = E_ACC && p.accumulate;
@@ -1012,27 +1080,38 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       }
     }
     if (fast) {
-      T* wl = wt + 4 * h * WN_COLS + l32;          // lane base; everything else below is an immediate
+      // lane base; everything else below is an immediate.  bf16 (M16): pixel mh*16 + 4*kb + r, column j*32 + nh*16 + m16
+      T* wl = wt + 4 * h * WN_COLS + l32;
+      T* wlb[NI][NH];       // bf16: rows 4*kb + (0..3) + 16*mh: their swap bit is kb & 1 for every immediate row offset
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) wlb[j][nh] = wt + wt_off(4 * kb, j * 32 + nh * 16 + m16);
       auto lean = [&](auto LR, auto ST) {
+        if constexpr (M16) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
+          for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-          for (int r2 = 0; r2 < 8; ++r2) {
-            const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2);                // rows row, row + 1 (+ 4h in wl)
-            f32x2 v = f32x2{acc[i][j][r], acc[i][j][r + 1]} + bv[j];
-            bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
-            v = __builtin_convertvector(q, f32x2);
-            if (decltype(ST)::value) { a1[j] += v; a2[j] += v * v; }
-            if (decltype(LR)::value) {
-              const f32x2 w = v * VG_LRELU_SLOPE;
-              f32x2 m;
-              asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
-              asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
-              q = __builtin_convertvector(m, bf16x2_t);
-            }
-            wl[row * WN_COLS + j * 32] = q[0];
-            wl[(row + 1) * WN_COLS + j * 32] = q[1];
-          }
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+              for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                  const int row = mh * 16 + r;                                    // rows row, row + 1 (+ 4kb in wl)
+                  f32x2 v = f32x2{acc4[i][mh][j][nh][r], acc4[i][mh][j][nh][r + 1]} + bv[j][nh];
+                  bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+                  v = __builtin_convertvector(q, f32x2);
+                  if (decltype(ST)::value) { a1[j][nh] += v; a2[j][nh] += v * v; }
+                  if (decltype(LR)::value) {
+                    const f32x2 w = v * VG_LRELU_SLOPE;
+                    f32x2 m;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
+                    q = __builtin_convertvector(m, bf16x2_t);
+                  }
+                  wlb[j][nh][row * WN_COLS] = q[0];
+                  wlb[j][nh][(row + 1) * WN_COLS] = q[1];
+                }
         }
       };
       if constexpr (sizeof(T) == 2) {
@@ -1043,20 +1122,26 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = n0 + (wn * NI + j) * 32 + l32;
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
-          float v = acc[i][j][r] + bv[j];
-          v = Elt<T>::to_f(Elt<T>::from_f(v));
-          if (rp[lrow] != 0xFFFFFFFFu) { a1[j][0] += v; a2[j][0] += v * v; }
-          if (act == VG_ACT_LRELU) v = vg_lrelu(v);
-          else if (act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
-          if (n >= p.Nout) v = 0.f;
-          wt[lrow * WN_COLS + j * 32 + l32] = Elt<T>::from_f(v);
+        for (int nh = 0; nh < NH; ++nh) {
+          const int col = j * 32 + (M16 ? nh * 16 + m16 : l32);
+          const int n = n0 + wn * WN_COLS + col;
+#pragma unroll
+          for (int r = 0; r < (M16 ? 8 : 16); ++r) {
+            int lrow;
+            float v;
+            if constexpr (M16) { lrow = (r >> 2) * 16 + 4 * kb + (r & 3); v = acc4[i][r >> 2][j][nh][r & 3]; }     // mh = r >> 2
+            else { lrow = (r & 3) + 8 * (r >> 2) + 4 * h; v = acc[i][j][r]; }
+            v += bv[j][nh];
+            v = Elt<T>::to_f(Elt<T>::from_f(v));
+            if (rp[lrow] != 0xFFFFFFFFu) { a1[j][nh][0] += v; a2[j][nh][0] += v * v; }
+            if (act == VG_ACT_LRELU) v = vg_lrelu(v);
+            else if (act == VG_ACT_SIGMOID) v = vg_sigmoid(v);
+            if (n >= p.Nout) v = 0.f;
+            wt[wt_off(lrow, col)] = Elt<T>::from_f(v);
+          }
         }
-      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1072,7 +1157,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         const int q = lane + 64 * rd;
         const int lrow = q / PPR, pc = q - lrow * PPR;
         pixr[rd] = rp[lrow];
-        stg[rd].v = *(const decltype(stg[rd].v)*)(wt + lrow * WN_COLS + pc * PIECE);
+        stg[rd].v = *(const decltype(stg[rd].v)*)(wt + wt_off(lrow, pc * PIECE));
       }
       const int ncol = n0 + wn * WN_COLS + (lane % PPR) * PIECE;      // 64 % PPR == 0: the same piece column in every round
       if (accumulate) {
@@ -1096,7 +1181,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
       const int n = n0 + wn * WN_COLS + pc * PIECE;
       if (pix == 0xFFFFFFFFu || n >= p.Ks) continue;
       Piece<T> o;
-      o.v = *(const decltype(o.v)*)(wt + lrow * WN_COLS + pc * PIECE);
+      o.v = *(const decltype(o.v)*)(wt + wt_off(lrow, pc * PIECE));
       T* dst = yg + (size_t)pix * p.Ks + n;
       if (accumulate) {
         Piece<T> old;
@@ -1167,15 +1252,18 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   VG_STAMP(3);
   if (want_stats) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const float t1 = a1[j][0] + a1[j][1], t2 = a2[j][0] + a2[j][1];
-      const float s1 = t1 + __shfl_xor(t1, 32, 64), s2 = t2 + __shfl_xor(t2, 32, 64);
-      if (h == 0) {
-        const int col = (wn * NI + j) * 32 + l32;
-        red[(wm * BN + col) * 2 + 0] = s1;
-        red[(wm * BN + col) * 2 + 1] = s2;
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int nh = 0; nh < NH; ++nh) {
+        const float t1 = a1[j][nh][0] + a1[j][nh][1], t2 = a2[j][nh][0] + a2[j][nh][1];
+        float s1 = t1 + __shfl_xor(t1, 32, 64), s2 = t2 + __shfl_xor(t2, 32, 64);
+        if constexpr (M16) { s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); }      // the four kb groups of a column
+        if (M16 ? kb == 0 : h == 0) {
+          const int col = (wn * NI + j) * 32 + (M16 ? nh * 16 + m16 : l32);
+          red[(wm * BN + col) * 2 + 0] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
+        }
       }
-    }
     __syncthreads();
     if (tid < BN && n0 + tid < p.Nout) {
       float t1 = 0.f, t2 = 0.f;
@@ -1510,6 +1598,9 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
     VG_T(0);
     f32x16 acc[2][2];                  // written by the MFMAs of the first K step (C = 0)
+#ifdef VG_EXP_MMA16
+    f32x4 accq[2][2][2];
+#endif
     const unsigned char* hb = smem + buf * HBYTES;
     // K loop, 36 steps of 4 MFMAs, fully unrolled; the two A fragments of step t+PD are requested before the MFMAs of
     // step t (one wave per SIMD: nobody else hides the LDS latency)
@@ -1541,6 +1632,14 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
       const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
       const bool in_a = ((tap * CCH + cc) * 2 + kk) * 2 + j < AFRAGS;
       static_assert(AFRAGS >= 2, "the first step's fragments are in accumulation registers");
+#ifdef VG_EXP_MMA16
+      for (int q = 0; q < 2; ++q) {
+        if (t == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(accq[i][j][q]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk][j]));
+        else if (in_a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][j][q]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk][j]));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][j][q]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk][j]));
+      }
+      return;
+#endif
       if (t == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[i][j]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk][j]));
       else if (in_a) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk][j]));
       else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk][j]));
@@ -1578,6 +1677,9 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
     __builtin_amdgcn_sched_barrier(0);
+#ifdef VG_EXP_MMA16
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = r < 8 ? accq[i][j][r >> 2][r & 3] : 0.f;
+#endif
     VG_T(1);
     // ---- epilogue (every tile is whole, all 64 channels are real: the launcher's conditions): BatchNorm statistics of
     // the bf16-rounded pre-activation, activation; both pixel rows into the wave's staging tile (stored next tile)
@@ -1803,6 +1905,9 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     tile_origin(tile, img, ty0, tx0);
     if (has_next) halo_begin(next);
     __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
+#ifdef VG_EXP_MMA16
+    f32x4 accq[TH][2];
+#endif
     f32x16 acc[TH];
     const unsigned char* hb = smem + buf * HBYTES;
     auto a_addr = [&](int t) {
@@ -1829,6 +1934,14 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     auto mfma = [&](int t, int i) {
       const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
       const bool in_a = (tap * CCH + cc) * 2 + kk < AFRAGS;        // 64 fragments in accumulation registers, 8 in ordinary ones
+#ifdef VG_EXP_MMA16
+      for (int q = 0; q < 2; ++q) {
+        if (t == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(accq[i][q]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk]));
+        else if (in_a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][q]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk]));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][q]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk]));
+      }
+      return;
+#endif
       if (t == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk]));
       else if (in_a) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk]));
       else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk]));
@@ -1869,6 +1982,9 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
     __builtin_amdgcn_sched_barrier(0);
+#ifdef VG_EXP_MMA16
+    for (int i = 0; i < TH; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = r < 8 ? accq[i][r >> 2][r & 3] : 0.f;
+#endif
     // ---- epilogue: statistics of the bf16-rounded pre-activation, activation; the four rows into the staging tile
     {
       f32x2 a1 = f32x2{0.f, 0.f}, a2 = f32x2{0.f, 0.f};
@@ -2736,7 +2852,7 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
         bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + hp * 64));
         bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64));
         const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tap], 0, 0, 0);
+        acc[tap] = Mma<bf16_t>::run(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, b), acc[tap]);
       }
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
@@ -2950,7 +3066,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
         bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + hp * 64));
         bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64));
         const bf16x8 bf = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-        acc[lt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf, acc[lt], 0, 0, 0);
+        acc[lt] = Mma<bf16_t>::run(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, bf), acc[lt]);
       }
       if (more) {
 #pragma unroll
