@@ -62,6 +62,9 @@ void vg_set_wgrad_kernel(int version);
 /* Name of the gather-GEMM kernel variant the calling thread's last vg_conv_fwd / vg_conv_dgrad launched
  * (e.g. "igemm3<bf16,4,2,2,4,3x3>"); bench.py keys its live per-kernel timings on it. */
 const char* vg_last_conv_kernel(void);
+/* The same for the calling thread's last vg_conv_wgrad ("wgrad3<4,2,1>", "wgrad3s2<4,1,1>", "wgrad<bf16,per-tap>"):
+ * parity tests assert which weight-gradient kernel they covered. */
+const char* vg_last_wgrad_kernel(void);
 
 /* ---- weight packing ---------------------------------------------------------------------- */
 /* Bytes of the packed forward (transposed=0) or dgrad (transposed=1) weight image. */
@@ -176,7 +179,9 @@ int vg_channel_sum(const void* a, int64_t rows, int cs, int c_valid, int dtype, 
  * static device array inside the library (256 KiB per GPU, held until the process ends), so there is no `ws`
  * argument and the call allocates nothing.  Limit: cs <= 1024 (VG_ERR_BAD_ARG beyond, with a message).  All calls on
  * one GPU share that array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream are
- * ordered and each clears what it uses. */
+ * ordered and each clears what it uses.  The FIRST call on a device resolves the array's address (hipGetSymbolAddress,
+ * which may load the code object): make one warm-up call per device outside any graph capture; every later call only
+ * enqueues a memset and two kernels.  Same layouts as vg_channel_sum, the bf16 cs == 4 image-side layout included. */
 int vg_channel_sum_noalloc(const void* a, int64_t rows, int cs, int c_valid, int dtype, float* out, int accumulate,
                            void* stream);
 
@@ -201,6 +206,13 @@ int vg_bn_finalize(const double* stats, int c, int cpad, int64_t count, const fl
 /* stats[VG_STATS_REPLICAS][2][cpad] (f64, zeroed by caller) += per-channel sum / sum of squares of x:
  * for a BatchNorm whose input is not a conv output (beta_vae_gans/model.py:117). */
 int vg_channel_stats(const void* x, double* stats, int64_t rows, int cs, int c, int cpad, int dtype, void* stream);
+/* Data parallel with global-batch statistics (no counterpart in the single-device reference, whose nn.BatchNorm2d sees
+ * the whole batch, e.g. vq_vae_gan/model.py:143-158): vg_stats_collapse reads the `nslots`
+ * accumulators of a [VG_STATS_REPLICAS][nslots] statistics buffer (nslots = 2 * cpad for a BatchNorm) into a dense f64
+ * vector, the only thing the ranks exchange (one all-reduce of nslots doubles); vg_stats_load puts the summed vector back
+ * into the buffer in the format the finalize kernels read (either accumulator mode, see vg_set_deterministic). */
+int vg_stats_collapse(const double* stats, int nslots, double* vec, void* stream);
+int vg_stats_load(const double* vec, int nslots, double* stats, void* stream);
 /* y = act(x*scale[c] + shift[c] (+ res)); act per VG_ACT_*.  x,res,y: [rows][cs] `dtype`. */
 int vg_bn_act_fwd(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t rows,
                   int cs, int c, int act, int dtype, void* stream);
@@ -363,7 +375,7 @@ size_t vg_augment_ws_bytes(const vg_aug_item* items, int n, int out_h, int out_w
  * workspace and output are device memory. */
 int vg_augment_batch(const vg_aug_item* items, int n, int out_h, int out_w, void* ws, size_t ws_bytes, float* out, void* stream);
 
-/* Backward of a wide Linear layer y = x W^T + b (beta_vae_gans/model.py:126-127 fc_mu / fc_logvar: 131072.. 524288 input
+/* Backward of a wide Linear layer y = x W^T + b (beta_vae_gans/model.py:74-75, 87-88 fc_mu / fc_logvar: 131072.. 524288 input
  * features, 128 outputs, a few dozen batch rows; all f32, row-major): one pass over the [fout][fin] matrix, no atomics.
  *   vg_linear_wgrad: dw[o][k] (+= if accumulate) = sum_b gy[b][o] * x[b][k]
  *   vg_linear_dgrad: dx[b][k] = sum_o gy[b][o] * w[o][k]

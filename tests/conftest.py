@@ -111,8 +111,10 @@ def check_state(g, sd, last_noise):
     constant (fresh running statistics) share the scale."""
     tol = max(1e-4, 4 * last_noise)
     for key, ref in g.items():
-        if key.startswith("sd:"):
+        if key.startswith("sd:") and np.asarray(ref).dtype.kind in "iu":
             assert int(sd[key[3:]]) == int(ref), key
+        elif key.startswith("sd:"):       # buffers stored whole (the quantiser's EMA state and codebook)
+            close_l2(sd[key[3:]], ref, rtol=tol, what=key[3:])
         elif key.startswith("sdd:"):
             k = key[4:]
             d = digest(k, sd[k])

@@ -9,6 +9,7 @@ both sides regenerate them with ``vae_gan_amd.testing.fill_state_dict`` from key
     python tests/golden/make_golden.py            # all fixtures
     python tests/golden/make_golden.py vq_step    # one group
 """
+import contextlib
 import importlib.util
 import os
 import sys
@@ -169,18 +170,35 @@ class _Bf16Storage:
     ``_unit_run``), and the conv / Linear weights the kernels read (``weights()``: the float masters are put back before
     the optimizer steps, as the engine keeps f32 masters and re-packs bf16 images after each step)."""
 
-    def __init__(self, model):
+    def __init__(self, model, sample=0):
         self.model, self.hooks = model, []
+        kinds = (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.LeakyReLU, torch.nn.Sigmoid)
+        # sample > 0: another, equally legitimate bf16 engine.  Two engines that differ only in the ORDER of their f32
+        # accumulation differ by ~2^-23 relative before the rounding to bf16, which decides the rounding (and, behind a
+        # LeakyReLU, the mask) of the few values that sit on a boundary: a relative jitter of that size before every
+        # rounding samples exactly that.
+        gen = torch.Generator().manual_seed(1000 + sample) if sample else None
+
+        def rnd(t):
+            if gen is not None and t.dtype.is_floating_point:
+                t = t * (1.0 + 2.0 ** -23 * torch.randn(t.shape, generator=gen, dtype=t.dtype))
+            return t.to(torch.bfloat16).to(t.dtype)
         for leaf in model.modules():
-            if isinstance(leaf, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.LeakyReLU, torch.nn.Sigmoid)):
-                self.hooks.append(leaf.register_forward_hook(lambda _m, _i, o: o.to(torch.bfloat16).to(o.dtype)))
+            if isinstance(leaf, kinds):
+                self.hooks.append(leaf.register_forward_hook(lambda _m, _i, o: rnd(o)))
+            if isinstance(leaf, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                # the engine's activations are bf16 tensors: whatever enters a convolution from outside the stack (the
+                # quantised latents, a reparameterised z, a concatenation with one) is rounded on entry (ops.to_nhwc);
+                # a no-op for what a hooked layer produced
+                self.hooks.append(leaf.register_forward_pre_hook(lambda _m, args: tuple(rnd(a) for a in args)))
 
     def weights(self):
         model = self.model
 
         class _W:
             def __enter__(w):
-                w.saved = [(p_, p_.data) for p_ in model.parameters() if p_.dim() >= 2]
+                w.saved = [(leaf.weight, leaf.weight.data) for leaf in model.modules()
+                           if isinstance(leaf, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.Linear))]
                 for p_, d in w.saved:
                     p_.data = d.to(torch.bfloat16).to(d.dtype)
 
@@ -217,7 +235,29 @@ def _ref_vq_step_bf16(model, images, opt_g, opt_d, st):
     return dl, gl, idx1, idx2, recon
 
 
-def _vq_step_run(dtype, iters=2, size=64, bf16_storage=False):
+N_BF16_SAMPLES = 8
+
+
+def _bf16_floor(run, truth):
+    """'noise_bf16:it0_*': how far the first iteration's scalars of the reference run with bf16 STORAGE are from the
+    exact run, the floor any bf16 engine has on them.  The discriminator's hinge loss sits behind a stack of LeakyReLU
+    masks (and, in the hierarchical model, a nearly one-hot softmax) and moves in steps with the rounding points, so one
+    run is one sample of a distribution: N_BF16_SAMPLES equally legitimate bf16 engines are run (sample 0: plain
+    round-to-nearest of fp64 values; the others: the same behind a 2^-23 relative jitter, i.e. another f32 accumulation
+    order, see _Bf16Storage) and the largest distance is recorded ('noise_bf16v:*' keeps them all)."""
+    out = {}
+    runs = [run(sample) for sample in range(N_BF16_SAMPLES)]
+    for k in runs[0]:
+        if k.startswith("it0_") and not k.endswith(("idx1", "idx2", "recon_img")):
+            d = [abs(float(r[k]) - float(truth[k])) / max(abs(float(truth[k])), 1e-12) for r in runs]
+            out["noise_bf16:" + k] = max(d)
+            out["noise_bf16v:" + k] = np.array(d)
+        if k == "it0_idx2":
+            out["idxeq_bf16:it0_idx2"] = float((runs[0][k] == truth[k]).float().mean())
+    return out
+
+
+def _vq_step_run(dtype, iters=2, size=64, bf16_storage=False, sample=0):
     m = load_ref("vq_vae_gan", "model")
     cfg = load_ref("vq_vae_gan", "config").Config()
     model = filled(m.VQVAEGAN(cfg)).to(dtype).train()
@@ -226,7 +266,7 @@ def _vq_step_run(dtype, iters=2, size=64, bf16_storage=False):
     opt_d = torch.optim.Adam(model.discriminator.parameters(), lr=cfg.lr / 2, betas=(cfg.beta1, cfg.beta2))
     images = synthetic_images(2, size, seed=42).to(dtype)
     out = {"images": images.float()}
-    st = _Bf16Storage(model) if bf16_storage else None
+    st = _Bf16Storage(model, sample) if bf16_storage else None
     for it in range(iters):
         if st is not None:
             dl, gl, idx1, idx2, recon = _ref_vq_step_bf16(model, images, opt_g, opt_d, st)
@@ -247,14 +287,12 @@ def g_vq_step(name="vq_step_64", iters=2, size=64):
     'noise_bf16:it0_*' = the first iteration's scalars of the reference run with bf16 STORAGE (_Bf16Storage) against
     the fp64 run: the floor a bf16 engine has on them (the bounds of the bf16 step tests derive from it)."""
     out, sd = _vq_step_run(torch.float32, iters, size)
-    out64, _ = _vq_step_run(torch.float64, iters, size)
-    outb, _ = _vq_step_run(torch.float64, 1, size, bf16_storage=True)
-    for k, v in outb.items():
-        if k.startswith("it0_") and not k.endswith(("idx1", "idx2", "recon_img")):
-            out["noise_bf16:" + k] = abs(v - out64[k]) / max(abs(out64[k]), 1e-12)
-            out["b:" + k] = v
-        if k == "it0_idx2":
-            out["idxeq_bf16:it0_idx2"] = float((v == out64[k]).float().mean())
+    out64, sd64 = _vq_step_run(torch.float64, iters, size)
+    # how far the reference's own fp32 run is from its fp64 run in the final state: Adam's lr * sign(g) on gradients that
+    # are rounding noise moves an element by +-lr whatever the arithmetic, so the digests carry a floor of their own
+    dn = [(digest(k_, sd[k_]), digest(k_, sd64[k_])) for k_ in sd if sd[k_].dtype != torch.int64]
+    out["noise:state"] = max(max(abs(a[0] - b[0]), abs(a[2] - b[2]) / 4) / max(float(b[0]), 1e-6) for a, b in dn)
+    out.update(_bf16_floor(lambda smp: _vq_step_run(torch.float64, 1, size, bf16_storage=True, sample=smp)[0], out64))
     for k, v in list(out.items()):
         if k.startswith("it") and not k.endswith(("idx1", "idx2", "recon_img")):
             out["noise:" + k] = abs(v - out64[k]) / max(abs(out64[k]), 1e-12)
@@ -367,28 +405,34 @@ def _adam_pair(model, cfg):
     return og, od
 
 
-def _beta_step_run(dtype, iters, images, eps):
+def _beta_step_run(dtype, iters, images, eps, bf16=None):
     """beta_vae_gans/main.py:75-108 around the reference model; D1: target = avg_pool2d(original, 2)."""
     m = load_ref("beta_vae_gans", "model")
     cfg = load_ref("beta_vae_gans", "config").Config()
     model = filled(m.BetaVAEGAN(cfg)).to(dtype).train()
     opt_g, opt_d = _adam_pair(model, cfg)
     images = images.to(dtype)
+    st = _Bf16Storage(model, bf16 - 1) if bf16 else None       # bf16 = 1 + sample number
+    wctx = st.weights if st else contextlib.nullcontext
+    if st:
+        images = images.to(torch.bfloat16).to(dtype)
     target = F.avg_pool2d(images, 2)
     out = {}
     for it in range(iters):
         opt_d.zero_grad()
-        with _InjectedNoise([eps[it]]):
-            recon, _, mu, logvar = model(images)
-        d_real = model.discriminator(images)
-        d_fake = model.discriminator(recon.detach())
-        dl = model.loss_function(target, recon, mu, logvar, d_real, d_fake, train_generator=False)
-        dl["total"].backward()
+        with wctx():
+            with _InjectedNoise([eps[it]]):
+                recon, _, mu, logvar = model(images)
+            d_real = model.discriminator(images)
+            d_fake = model.discriminator(recon.detach())
+            dl = model.loss_function(target, recon, mu, logvar, d_real, d_fake, train_generator=False)
+            dl["total"].backward()
         opt_d.step()
         opt_g.zero_grad()
-        d_fake = model.discriminator(recon)
-        gl = model.loss_function(target, recon, mu, logvar, d_real, d_fake, train_generator=True)
-        gl["total"].backward()
+        with wctx():
+            d_fake = model.discriminator(recon)
+            gl = model.loss_function(target, recon, mu, logvar, d_real, d_fake, train_generator=True)
+            gl["total"].backward()
         opt_g.step()
         out.update({f"it{it}_d_loss": dl["total"].item(), f"it{it}_g_loss": gl["total"].item(), f"it{it}_recon": gl["recon"],
                     f"it{it}_kl": gl["kl"], f"it{it}_adv": gl["adv"], f"it{it}_recon_img": recon.detach().clone().float()})
@@ -415,7 +459,7 @@ def _nearest_decoder(dec):
     return forward
 
 
-def _hier_step_run(dtype, iters, images, eps):
+def _hier_step_run(dtype, iters, images, eps, bf16=None):
     """hierarchical_vae_gan/main.py:75-111 around the reference model with D2 (decoder) and D1 (target)."""
     m = load_ref("hierarchical_vae_gan", "model")
     cfg = load_ref("hierarchical_vae_gan", "config").Config()
@@ -423,23 +467,29 @@ def _hier_step_run(dtype, iters, images, eps):
     model.decoder.forward = _nearest_decoder(model.decoder)
     opt_g, opt_d = _adam_pair(model, cfg)
     images = images.to(dtype)
+    st = _Bf16Storage(model, bf16 - 1) if bf16 else None       # bf16 = 1 + sample number
+    wctx = st.weights if st else contextlib.nullcontext
+    if st:
+        images = images.to(torch.bfloat16).to(dtype)
     target = F.avg_pool2d(images, 2)
     out = {}
     for it in range(iters):
         opt_d.zero_grad()
-        with _InjectedNoise(eps[it][0]):
-            recon, _, mu_l, lv_l = model(images)
-        d_real = model.discriminator(images)
-        d_fake = model.discriminator(recon.detach())
-        dl = model.loss_function(target, recon, mu_l, lv_l, d_real, d_fake, train_generator=False)
-        dl["total"].backward()
+        with wctx():
+            with _InjectedNoise(eps[it][0]):
+                recon, _, mu_l, lv_l = model(images)
+            d_real = model.discriminator(images)
+            d_fake = model.discriminator(recon.detach())
+            dl = model.loss_function(target, recon, mu_l, lv_l, d_real, d_fake, train_generator=False)
+            dl["total"].backward()
         opt_d.step()
         opt_g.zero_grad()
-        with _InjectedNoise(eps[it][1]):
-            recon, _, mu_l, lv_l = model(images)
-        d_fake = model.discriminator(recon)
-        gl = model.loss_function(target, recon, mu_l, lv_l, d_real, d_fake, train_generator=True)
-        gl["total"].backward()
+        with wctx():
+            with _InjectedNoise(eps[it][1]):
+                recon, _, mu_l, lv_l = model(images)
+            d_fake = model.discriminator(recon)
+            gl = model.loss_function(target, recon, mu_l, lv_l, d_real, d_fake, train_generator=True)
+            gl["total"].backward()
         opt_g.step()
         out.update({f"it{it}_d_loss": dl["total"].item(), f"it{it}_d_kl": dl["kl"], f"it{it}_g_loss": gl["total"].item(),
                     f"it{it}_recon": gl["recon"], f"it{it}_kl": gl["kl"], f"it{it}_adv": gl["adv"],
@@ -606,8 +656,28 @@ def g_layer_units():
     save("layer_units", **out)
 
 
+def g_bf16_floors():
+    """Add 'noise_bf16:it0_*' (see _bf16_floor) to the three committed whole-step goldens; every other entry stays as it
+    is.  The truth is the golden's own first-iteration scalars (the reference's fp32 run: 1e-7 from its fp64 run)."""
+    def merge(name, run):
+        path = os.path.join(HERE, name + ".npz")
+        z = np.load(path, allow_pickle=False)
+        old = {k: z[k] for k in z.files if not k.startswith(("noise_bf16", "idxeq_bf16"))}
+        truth = {k: torch.as_tensor(v) if k.endswith("idx2") else float(v) for k, v in old.items()
+                 if k.startswith("it0_") and not k.endswith(("idx1", "recon_img"))}
+        add = _bf16_floor(run, truth)
+        np.savez_compressed(path, **old, **{k: np.asarray(v) for k, v in add.items()})
+        print(name, {k: (v if np.ndim(v) == 0 else list(v)) for k, v in add.items()})
+    merge("vq_step_64", lambda smp: _vq_step_run(torch.float64, 1, 64, bf16_storage=True, sample=smp)[0])
+    img_h = synthetic_images(2, 128, seed=47)
+    merge("hier_step_128", lambda smp: _hier_step_run(torch.float64, 1, img_h, hier_step_eps(2, 128), bf16=1 + smp)[0])
+    img_b = synthetic_images(2, 256, seed=46)
+    merge("beta_step_256", lambda smp: _beta_step_run(torch.float64, 1, img_b, [synthetic_eps((2, 128), 60)], bf16=1 + smp)[0])
+    merge("vq_step_256", lambda smp: _vq_step_run(torch.float64, 1, 256, bf16_storage=True, sample=smp)[0])
+
+
 GROUPS = {"layer_units": g_layer_units, "vq_quantizer": g_vq_quantizer, "resblock": g_resblock, "vq_modules": g_vq_modules,
-          "vq_step": g_vq_step, "vq_step_256": g_vq_step_256, "losses": g_losses, "beta_modules": g_beta_modules,
+          "vq_step": g_vq_step, "vq_step_256": g_vq_step_256, "bf16_floors": g_bf16_floors, "losses": g_losses, "beta_modules": g_beta_modules,
           "hier_modules": g_hier_modules, "beta_step": g_beta_step, "hier_step": g_hier_step, "vq_codec": g_vq_codec, "augment": g_augment}
 
 if __name__ == "__main__":

@@ -39,6 +39,9 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"{arch}: host {1e2 * (t1 - t0):.2f} ms/step, total {1e2 * (t2 - t0):.2f} ms/step", flush=True)
+# the backward functions run on the autograd engine's own thread, where cProfile (per thread) does not see them: for the
+# profile alone, make the engine call them on this thread
+torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):

@@ -137,3 +137,30 @@ def test_dp_global_statistics_hook_world2():
     out = mp.Manager().dict()
     mp.spawn(_worker_stats, args=(world, port, out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_device_loader_reshuffles_every_epoch_with_world_gt_1(tmp_path):
+    """under torchrun every rank walked its shard in the same order in every epoch (nothing called
+    DistributedSampler.set_epoch).  DeviceLoader.set_epoch, called by loop.train at the top of each epoch, makes the
+    order a function of the epoch, like the single-process loader's shuffle=True and the reference's (data.py:133-139)."""
+    from PIL import Image
+    import numpy as np
+    from vae_gan_amd import data as D
+    d = tmp_path / "kodak"
+    d.mkdir()
+    for i in range(12):
+        Image.fromarray(np.full((8, 8, 3), i, dtype=np.uint8)).save(d / f"kodim{i:02d}.png")
+
+    class Cfg:
+        data_dir, dataset, image_size, seed, batch_size, eval_batch_size, num_workers = str(tmp_path), "kodak", 8, 42, 2, 1, 0
+
+    loader = D.get_dataloader(Cfg(), "train", rank=1, world=2)
+    loader.transform = lambda images: [int(im[0, 0, 0]) for im in images]       # no GPU here: just which files came
+    orders = []
+    for epoch in range(2):
+        loader.set_epoch(epoch)
+        orders.append([i for batch in loader for i in batch])
+    assert sorted(orders[0]) != list(range(12)) and len(orders[0]) == 6         # a shard of half the files
+    assert orders[0] != orders[1], "the same order in both epochs"
+    loader.set_epoch(0)
+    assert [i for batch in loader for i in batch] == orders[0]                 # reproducible per (seed, epoch)

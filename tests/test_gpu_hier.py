@@ -208,6 +208,7 @@ def test_hier_step_bf16_close_to_reference(vg):
     from vae_gan_amd.hierarchical_vae_gan.model import HierarchicalVAEGAN
     from vae_gan_amd.testing import fill_state_dict, hier_step_eps
     from vae_gan_amd.train import build_optimizers, hier_train_step
+    from test_gpu_step import bf16_bound
     vg.set_compute_dtype(torch.bfloat16)
     try:
         g = load_golden("hier_step_128")
@@ -223,7 +224,7 @@ def test_hier_step_bf16_close_to_reference(vg):
         torch.cuda.synchronize()
         for k, v in {"d_loss": dl["total"], "d_kl": dl["kl"], "g_loss": gl["total"], "recon": gl["recon"], "kl": gl["kl"]}.items():
             ref = float(g[f"it0_{k}"])
-            tol = 6e-2 if k == "d_loss" else 2e-2
+            tol = bf16_bound(g, k)       # max(2e-2, 1.5 x the largest of the reference's own 8 bf16-storage samples): d_loss 5.5e-2
             assert abs(float(v.detach()) - ref) <= tol * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
         assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
     finally:

@@ -3,7 +3,7 @@ against the golden captured from the reference model + torch.optim.Adam (two ite
 import pytest
 import torch
 
-from conftest import load_golden, as_t, close_l2
+from conftest import load_golden, as_t, close_l2, check_state
 from vae_gan_amd.testing import fill_state_dict, digest
 
 pytestmark = pytest.mark.gpu
@@ -41,28 +41,17 @@ def test_vq_step_f32_matches_reference():
             assert abs(float(v.detach()) - ref) <= tol * max(abs(ref), 1e-3), (it, k, float(v.detach()), ref, tol)
         match = (idx2.cpu() == as_t(g[f"it{it}_idx2"])).float().mean().item()
         assert match >= (1.0 if it == 0 else float(g["idxeq64:it1_idx2"]) - 0.02), (it, match)
-    sd = model.state_dict()
-    noise = max(float(g["noise:it1_recon_img"]), 1e-4)
-    for key, ref in g.items():
-        if key.startswith("sd:") and sd[key[3:]].dtype == torch.int64:
-            assert int(sd[key[3:]]) == int(ref), key       # BN counters: generator +2/iter, discriminator +3/iter
-        elif key.startswith("sdd:"):
-            d = digest(key[4:], sd[key[4:]])
-            assert abs(d[0] - ref[0]) <= max(1e-4, 4 * noise) * max(ref[0], 1e-6), key
+    # BatchNorm counters exactly (generator +2 / iteration, discriminator +3), every other entry by norm AND probe dot
+    check_state(g, model.state_dict(), float(g["noise:it1_recon_img"]))
     from vae_gan_amd import ops
     ops.set_compute_dtype(torch.bfloat16)
 
 
 def test_vq_step_bf16_close_to_reference():
-    """bf16 mode: first-iteration losses within 2e-2 of the fp32 reference (north_star bf16 tolerance).
-
-    The discriminator's hinge loss gets 3e-2: at random init it is 2 + (mean D(fake) - mean D(real)) with logit means of
-    ~1e-2, so the bound is one on the ABSOLUTE error of the logit means (0.06), and those carry bf16 storage through five
-    conv + train-mode BatchNorm layers on a 4-image batch.  Measured: 1.9 % and 2.5 % below the reference with two kernel
-    selections whose forward tensors differ only in the last bit of the BatchNorm sums (tests/gpu_dl_diag.py) - the value
-    is chaotic at the 0.6 % level in bf16, and the reference's own modules run with bf16 storage sit 2.6e-2..5.1e-2 from
-    fp64 on every unit with a LeakyReLU.  The tight bf16 checks are the per-layer ones
-    (tests/test_gpu_layer_grads.py), held against a bf16-storage run of the reference."""
+    """bf16 mode: first-iteration losses within 2e-2 of the fp32 reference (north_star bf16 tolerance), except where the
+    reference's own bf16-storage runs are further from it than that (bf16_bound: the discriminator's hinge loss, 4.2e-2
+    here = 1.5 x the largest of the reference's eight samples, 2.8 %; the engine measures 1.9-2.5 %).  The tight bf16
+    checks are the per-layer ones (tests/test_gpu_layer_grads.py), held against a bf16-storage run of the reference."""
     from vae_gan_amd.train import vq_train_step
     g = load_golden("vq_step_64")
     model, opt_g, opt_d = _setup(torch.bfloat16)
@@ -71,7 +60,72 @@ def test_vq_step_bf16_close_to_reference():
     torch.cuda.synchronize()
     for k, v in {"d_loss": dl["total"], "g_loss": gl["total"], "recon": gl["recon"], "vq": gl["vq"]}.items():
         ref = float(g[f"it0_{k}"])
-        assert abs(float(v.detach()) - ref) <= (3e-2 if k == "d_loss" else 2e-2) * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
+        assert abs(float(v.detach()) - ref) <= bf16_bound(g, k) * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def bf16_bound(g, k):
+    """north_star's 2e-2, or 1.5 x the largest distance of the REFERENCE's own bf16-storage runs from its exact run where
+    that is larger.  'noise_bf16:it0_*' in the goldens (make_golden.py:_bf16_floor) is the largest of EIGHT runs of the
+    reference modules with bf16 storage, which differ only by a 2^-23 relative jitter before each rounding (= another f32
+    accumulation order): the discriminator's hinge loss sits behind a stack of LeakyReLU masks (hierarchical: and a nearly
+    one-hot softmax) and moves in steps with the rounding points - the reference's own eight samples span 0.3 % .. 2.8 %
+    (vq_step_64) and 0.2 % .. 3.7 % (hier_step_128), every other scalar stays below 0.7 %.  DESIGN.md section 2 has the
+    table of bounds, floors and measured values (tests/gpu_bf16_margins.py prints it)."""
+    return max(2e-2, 1.5 * float(g[f"noise_bf16:it0_{k}"]))
+
+
+def _profiled_kernels(fn):
+    """Run fn() with a KernelProfile installed; the set of kernel variants the library dispatched."""
+    from vae_gan_amd import ops
+    prof = ops.KernelProfile()
+    ops.PROFILE[0] = prof
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILE[0] = None
+    return out, {name for name, _, _, _ in prof.records}
+
+
+def test_vq_step_256_f32_matches_reference():
+    """one iteration of the reference step (vq_vae_gan/main.py:75-111) at the reference's own
+    image_size = 256 (B = 2), where the layer shapes are those of the benchmarked configuration."""
+    from vae_gan_amd.train import vq_train_step
+    from vae_gan_amd import ops
+    g = load_golden("vq_step_256")
+    model, opt_g, opt_d = _setup(torch.float32)
+    images = as_t(g["images"]).cuda()
+    dl, gl, idx2 = vq_train_step(model, images, opt_g, opt_d)
+    torch.cuda.synchronize()
+    mine = {"d_loss": dl["total"], "d_recon": dl["recon"], "g_loss": gl["total"], "recon": gl["recon"], "vq": gl["vq"], "adv": gl["adv"]}
+    for k, v in mine.items():
+        ref = float(g[f"it0_{k}"])
+        tol = max(1e-4, 4 * float(g[f"noise:it0_{k}"]))
+        scale = max(abs(ref), 1e-3, abs(float(g["it0_d_loss"])) if k == "adv" else 0.0)     # adv: a mean of signed logits
+        assert abs(float(v.detach()) - ref) <= tol * scale, (k, float(v.detach()), ref, tol)
+    assert torch.equal(idx2.cpu(), as_t(g["it0_idx2"]))                    # 2 x 32 x 32 code indices, bit-exact
+    check_state(g, model.state_dict(), float(g["noise:state"]))      # the reference's own fp32-vs-fp64 distance in the final state
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+def test_vq_step_256_bf16_runs_the_benchmarked_kernels():
+    """bf16 mode at 256 x 256: first-iteration losses within the bf16 bounds of the fp32 reference, and the step went
+    through the kernels bench.py measures: the test names the kernel variants it covered (vg_last_conv_kernel /
+    vg_last_wgrad_kernel per launch), so a change of the selection rules cannot silently move it off them."""
+    from vae_gan_amd.train import vq_train_step
+    g = load_golden("vq_step_256")
+    model, opt_g, opt_d = _setup(torch.bfloat16)
+    images = as_t(g["images"]).cuda()
+    (dl, gl, idx2), kernels = _profiled_kernels(lambda: vq_train_step(model, images, opt_g, opt_d))
+    for k, v in {"d_loss": dl["total"], "g_loss": gl["total"], "recon": gl["recon"], "vq": gl["vq"]}.items():
+        ref = float(g[f"it0_{k}"])
+        assert abs(float(v.detach()) - ref) <= bf16_bound(g, k) * max(abs(ref), 1e-3), (k, float(v.detach()), ref)
+    match = (idx2.cpu() == as_t(g["it0_idx2"])).float().mean().item()
+    assert match >= float(g["idxeq_bf16:it0_idx2"]) - 0.05, match           # the reference's own bf16-storage run keeps this share
+    for want in ("igemm3<bf16,4,2,4,2,3x3>", "igemm3<bf16,4,2,4,2,2x2>", "igemm3s2<bf16,", "igemm4<bf16,3x3", "igemm4c<bf16,3x3",
+                 "igemm4p<bf16,2x2", "thin_conv", "conv1", "wgrad3<4,2,1>", "wgrad3<2,2,2>", "wgrad3s2<"):
+        assert any(n.startswith(want) for n in kernels), (want, sorted(kernels))
     assert all(torch.isfinite(p).all() for p in model.parameters())
 
 

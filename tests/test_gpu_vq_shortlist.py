@@ -126,3 +126,32 @@ def test_shortlist_rejects_bad_arguments(lib):
     t = torch.zeros(1024, device="cuda")
     i = torch.zeros(16, dtype=torch.int64, device="cuda")
     assert lib.vg_vq_assign_shortlist(t.data_ptr(), t.data_ptr(), 4, 4, 48, i.data_ptr(), t.data_ptr(), None, L.stream()) != 0
+
+
+def test_shortlist_worst_case_rounding(lib):
+    """Aligned worst-case bf16 rounding: every coordinate of z and of the winning code W sits just beside
+    a bf16 midpoint, with the signs arranged so that ALL rounding errors make z.W look smaller (31 coordinates positive
+    and rounding down, 31 with a negative product and rounding up in magnitude), while the exact z.W nearly cancels
+    (one exactly representable coordinate tips it to ~ +5e-4 .. +9e-4); the runner-up X = -W gets the same error with the
+    opposite sign.  The bf16 distances then order the pair wrongly by ~2^-6 |z| (|W| + |X|) = 1.94 against an exact gap of
+    4 z.W ~ 3e-3 the other way: the per-code bound must be (2^-6 + 2^-15) |z||E_k| for pass 2 to keep W.  With round 2's
+    constant (1.02 * 2^-7: the two bounds sum to 1.0) W is dropped and X comes out."""
+    d, k, rows = 64, 64, 48
+    u = 2.0 ** -23
+    w = torch.zeros(d, dtype=torch.float64)
+    a0, b0 = 1 + 2.0 ** -8 - 8 * u, 1 + 2.0 ** -8 + 8 * u      # just below / just above the midpoint of 1 and 1 + 2^-7
+    w[:31], w[31:62], w[62] = a0, -b0, 2.0 ** -5
+    zs = torch.zeros(rows, d, dtype=torch.float64)
+    for r in range(rows):                                    # the same construction at 48 distances from the midpoints
+        e = (8 + r) * u
+        zs[r, :31], zs[r, 31:62], zs[r, 62] = 1 + 2.0 ** -8 - e, 1 + 2.0 ** -8 + e, 2.0 ** -5
+    assert float((zs @ w).min()) > 4e-4                      # W (code 0) beats -W (code 1) for every row, exactly
+    g = torch.Generator().manual_seed(3)
+    cb = torch.randn(k, d, generator=g, dtype=torch.float64) * 100.0        # everybody else is far away
+    cb[0], cb[1] = w, -w
+    zf, cf = zs.float().cuda().contiguous(), cb.float().cuda().contiguous()
+    assert torch.equal(zf[:, :63].double().cpu(), zs[:, :63]) and torch.equal(cf[:2].double().cpu(), cb[:2])     # exact in f32
+    ref, out, flag = _both(lib, zf, cf)
+    assert torch.equal(ref.cpu(), torch.zeros(rows, dtype=torch.int64)), "the exact search must pick W (code 0)"
+    assert torch.equal(ref, out), f"{int((ref != out).sum())} of {rows} worst-case rows lost their argmin"
+    assert flag == 0

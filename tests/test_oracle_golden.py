@@ -140,6 +140,25 @@ def test_vq_full_step():
             assert abs(d[0] - ref[0]) <= max(1e-4, 4 * last_noise) * max(ref[0], 1e-6), k
 
 
+def test_vq_full_step_256():
+    """one iteration at the reference's own image_size = 256 (B = 2): the oracle against the
+    reference-made golden, so that the GPU test of the same golden (tests/test_gpu_step.py) has a pinned checker."""
+    g = load_golden("vq_step_256")
+    sd = fill_state_dict(O.vq_template())
+    r = O.vq_train_step(sd, as_t(g["images"]), O.VQ_DEFAULT_CFG, {"g": {}, "d": {}})
+    for k in ("d_loss", "d_recon", "g_loss", "recon", "vq", "adv"):
+        ref = float(g[f"it0_{k}"])
+        tol = max(1e-4, 4 * float(g[f"noise:it0_{k}"]))
+        scale = max(abs(ref), 1e-3, abs(float(g["it0_d_loss"])) if k == "adv" else 0.0)
+        assert abs(r[k] - ref) <= tol * scale, (k, r[k], ref, tol)
+    for nm in ("idx1", "idx2"):
+        assert torch.equal(r[nm], as_t(g[f"it0_{nm}"])), nm
+    close_l2(r["recon_img"], g["it0_recon_img"], g["noise:it0_recon_img"], what="recon")
+    for key, ref in g.items():
+        if key.startswith("sd:") and sd[key[3:]].dtype == torch.int64:
+            assert int(sd[key[3:]]) == int(ref), key
+
+
 def test_losses():
     g = load_golden("losses")
     mu, lv, eps = as_t(g["mu"]), as_t(g["logvar"]), as_t(g["eps"])

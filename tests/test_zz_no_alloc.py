@@ -31,7 +31,9 @@ def test_noalloc_channel_sum_matches_workspace_entry_point():
     # first call: the largest supported stride (1024 channels, bf16), many rows; second call: smaller in every way
     big = torch.randn(3000, 1024, device="cuda", generator=g).to(torch.bfloat16)
     small = torch.randn(257, 48, device="cuda", generator=g)               # f32, stride 48, 41 valid channels
-    for t, c_valid, acc in ((big, 1024, 0), (small, 41, 1), (big[:, :512].contiguous(), 500, 0), (small[:5].contiguous(), 48, 0)):
+    thin = torch.randn(70000, 4, device="cuda", generator=g).to(torch.bfloat16)      # the bf16 image-side layout (8-byte pixels)
+    for t, c_valid, acc in ((big, 1024, 0), (small, 41, 1), (big[:, :512].contiguous(), 500, 0), (small[:5].contiguous(), 48, 0),
+                            (thin, 3, 0), (thin[:100].contiguous(), 3, 1)):
         want, got = _both(lib, L, t, c_valid, acc, seed=c_valid)
         ref = t.double().sum(0)[:c_valid]
         if acc:

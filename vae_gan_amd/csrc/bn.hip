@@ -584,3 +584,39 @@ extern "C" int vg_channel_stats(const void* x, double* stats, int64_t rows, int 
   VG_LAUNCH_CHECK();
   return VG_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Statistics exchange for data parallel runs with global-batch statistics (train.DataParallel(bn_sync='global')): what
+// has to travel between the ranks is ONE value per accumulator (sum x, sum x^2 per channel: SURVEY.md section 5), not the
+// 32 replicas / 22 fixed-point bins it is spread over on the device.  vg_stats_collapse reads every accumulator the way
+// the finalize kernels do (fixed order) into a dense f64 vector; after the all-reduce vg_stats_load puts the vector
+// back: plain mode = replica 0, the others cleared; reproducible mode = cut exactly into the fixed-point bins (a double
+// is at most three f32 pieces), so everything downstream reads the accumulator as before.  A non-finite value travels
+// as NaN and raises the marker slot again.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stats_collapse_kernel(const double* __restrict__ stats, int nslots, double* __restrict__ vec, int det) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nslots) vec[i] = vg_acc_read(stats + i, (size_t)nslots, det);
+}
+__global__ __launch_bounds__(256) void stats_load_kernel(const double* __restrict__ vec, int nslots, double* __restrict__ stats, int det) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nslots) return;
+  const double v = vec[i];
+#pragma unroll
+  for (int r = 0; r < VG_STATS_REPLICAS; ++r) stats[(size_t)r * nslots + i] = 0.0;      // all-zero bits in both formats
+  if (!det) stats[i] = v;
+  else vg_acc_add(stats + i, (size_t)nslots, 0u, v, det);       // this thread owns accumulator i: its own stores are ordered before its atomics
+}
+extern "C" int vg_stats_collapse(const double* stats, int nslots, double* vec, void* stream) {
+  VG_REQUIRE(stats && vec && nslots > 0, "stats_collapse: bad arguments");
+  hipLaunchKernelGGL(stats_collapse_kernel, dim3((nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, stats, nslots, vec, vg_det_mode());
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}
+extern "C" int vg_stats_load(const double* vec, int nslots, double* stats, void* stream) {
+  VG_REQUIRE(stats && vec && nslots > 0, "stats_load: bad arguments");
+  hipLaunchKernelGGL(stats_load_kernel, dim3((nslots + 255) / 256), dim3(256), 0, (hipStream_t)stream, vec, nslots, stats, vg_det_mode());
+  VG_LAUNCH_CHECK();
+  return VG_OK;
+}

@@ -94,15 +94,29 @@ template <> struct Piece<bf16_t> {
 //             (exactly), a piece M * 2^(E-150) (24-bit mantissa M) is added as the integer M << (E % 24) to bin E / 24
 //             (VG_DET_BINS bins x 2 sub-replicas fill 22 of the 32 replica slots).  Integer addition is associative, so
 //             the slots, and everything computed from them, are the same bits on every run.  47-bit addends leave room
-//             for 2^16 adds per slot.  Pieces below 2^-126 are dropped.
+//             for 2^16 adds per slot: with the two sub-replicas a launch may add from 2^17 blocks per channel, and every
+//             launcher that hands `det` to a kernel checks its block count first (VG_DET_GUARD).  Pieces below 2^-126
+//             are dropped.  A partial sum that is not finite (or beyond the f32 range) raises the marker slot
+//             VG_DET_NAN_SLOT instead, and the read then returns NaN, as the f64 atomics would have propagated it.
 // vg_stats_read sums the slots in a fixed order either way.  (vg_api.h: vg_set_deterministic.)
 // ---------------------------------------------------------------------------------------------
 #define VG_DET_BINS 11
+#define VG_DET_NAN_SLOT (2 * VG_DET_BINS)
+#define VG_DET_MAX_BLOCKS (1L << 17)
 int vg_det_mode(void);      // host: the library-wide switch (pack.hip)
+// host: refuse a launch whose block count could overflow a fixed-point slot (adds per channel <= blocks)
+#define VG_DET_GUARD(blocks)                                                                                         \
+  VG_REQUIRE(!vg_det_mode() || (long)(blocks) <= VG_DET_MAX_BLOCKS,                                                  \
+             "deterministic statistics: %ld blocks add to one accumulator, the fixed-point slots hold %ld (split the batch)", \
+             (long)(blocks), VG_DET_MAX_BLOCKS)
 // slot0 = replica 0 of the accumulator, rep_stride = distance (in slots) between replicas
 __device__ inline void vg_acc_add(double* slot0, size_t rep_stride, unsigned hint, double v, int det) {
   if (!det) {
     unsafeAtomicAdd(&slot0[(size_t)(hint % VG_STATS_REPLICAS) * rep_stride], v);
+    return;
+  }
+  if (!(fabs(v) <= 3.4e38)) {                      // NaN, infinity, or beyond what the f32 pieces can carry
+    atomicOr((unsigned long long*)&slot0[(size_t)VG_DET_NAN_SLOT * rep_stride], 1ull);
     return;
   }
 #pragma unroll 1
@@ -132,11 +146,12 @@ __device__ inline double vg_acc_read(const double* slot0, size_t rep_stride, int
   }
   const long long* q = (const long long*)slot0;
   long long t[VG_DET_BINS];
+  const long long bad = q[(size_t)VG_DET_NAN_SLOT * rep_stride];
 #pragma unroll
   for (int b = 0; b < VG_DET_BINS; ++b) t[b] = q[(size_t)b * rep_stride] + q[(size_t)(b + VG_DET_BINS) * rep_stride];
 #pragma unroll
   for (int b = VG_DET_BINS - 1; b >= 0; --b) s += ldexp((double)t[b], 24 * b - 150);
-  return s;
+  return bad ? __builtin_nan("") : s;
 }
 // the [VG_STATS_REPLICAS][2][cpad] layout of the BatchNorm sums (which: 0 = first sum, 1 = second)
 __device__ inline void vg_stats_add(double* stats, int cpad, int which, int ch, unsigned hint, double v, int det) {

@@ -141,6 +141,17 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_byte_of
                : "s"(lds_byte_off), "v"(gsrc)
                : "memory");
 }
+// The same with the global address as a wave-uniform base (an SGPR pair) plus a 32-bit per-lane byte offset: one
+// address register per outstanding piece instead of two, and no 64-bit vector add per piece.  (igemm3 kept one 64-bit
+// per-lane pointer per halo round live across its K loop; with the 16x16x32 accumulators two of them spilled, and every
+// reload came with an `s_waitcnt vmcnt(0)` that drained the DMA ring: +7 % cycles.)
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, unsigned lds_byte_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_byte_off), "v"(voff), "s"(sbase)
+               : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
@@ -686,7 +697,10 @@ struct Igemm3Cfg {
   static constexpr int NT = 512, TW = 32, TH = MI * WM, BM = TH * TW, BN = 32 * NI * WN;
   static constexpr int EB = sizeof(T), KC = 64 / EB, PIECE = 16 / EB;
   static constexpr int NTAPS = R * S, PF = 3, NSB = PF + 2;
-  static constexpr int NPH = (MI * NI == 8) ? 2 : 1;          // phases per K tile, 8 MFMA blocks each (16 per phase: no faster)
+  // phases per K tile: two of 16 MFMAs (16x16x32) for the 128 x 64 wave tile, except on the 2x2 tap grid, where one phase
+  // of 32 runs the stride-2 forwards 2-4 % faster and the transposed phases the same (the 3x3 kernels spill with the second
+  // phase's B fragments live: 1293 -> 1062 TFLOP/s)
+  static constexpr int NPH = (MI * NI == 8 && R * S != 4) ? 2 : 1;
   static constexpr int KPP = 2 / NPH;                         // 16-byte fragment steps per phase
   static constexpr int BSTRIDE = BN * 64;
   static constexpr int LPB = (BN * 4 + NT - 1) / NT;          // weight DMA instructions per wave per K tile
@@ -869,19 +883,22 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-  // ---- DMA helpers; tap / round arguments are compile-time after unrolling
+  // ---- DMA helpers; tap / round arguments are compile-time after unrolling.  Weight pieces and (stride-1) halo pieces
+  // go out as wave-uniform base + 32-bit lane offset (lds_dma16_s): the compiler does not see these DMAs, every wait
+  // for them is one of the kernel's own counted vmcnt waits.
+  const unsigned smem0 = lds_addr_of(smem);
   auto dma_b = [&](int i, int itap, int icc, int slot) {
     const unsigned char* src;
     if constexpr (S2) {
       const int plane = icc >> p.lgc, ic = icc & (cch - 1);
       const int rs = (2 * (itap >> 1) + (plane >> 1)) * 4 + 2 * (itap & 1) + (plane & 1);
-      src = wg + ((size_t)rs * cbytes + (size_t)ic * 64) + boff[i];
+      src = wg + ((size_t)rs * cbytes + (size_t)ic * 64);
     } else {
-      src = wg + ((size_t)itap * cbytes + (size_t)icc * 64) + boff[i];
+      src = wg + ((size_t)itap * cbytes + (size_t)icc * 64);
     }
-    if (VG_DBG(16)) src = wg + boff[i];        // timing ablation: every weight tile from the same (cache-hot) 8-16 KB
-    unsigned char* dst = smem + SB_OFF + slot * BSTRIDE + (i * NT + wave * BLANES) * 16;
-    if (BLANES == 64 || lane < BLANES) __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    if (VG_DBG(16)) src = wg;                  // timing ablation: every weight tile from the same (cache-hot) 8-16 KB
+    const unsigned dst = smem0 + SB_OFF + slot * BSTRIDE + (i * NT + wave * BLANES) * 16;
+    if (BLANES == 64 || lane < BLANES) lds_dma16_s(src, boff[i], dst);
   };
   auto dma_h = [&](int rd, int icc, int hboff) {
     if constexpr (S2) {
@@ -892,9 +909,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(smem + hboff + (rd * NT + wave * 64) * 16), 16, 0, 0);
       }
     } else {
-      if (poff[rd] != 0xFFFFFFFFu)
-        __builtin_amdgcn_global_load_lds((gptr_t)(xg + (size_t)icc * 64 + poff[rd]),
-                                         (lds_ptr_t)(smem + hboff + (rd * NT + wave * 64) * 16), 16, 0, 0);
+      if (poff[rd] != 0xFFFFFFFFu) lds_dma16_s(xg + (size_t)icc * 64, poff[rd], smem0 + hboff + (rd * NT + wave * 64) * 16);
     }
   };
   // halo rounds of chunk icc that ride on the prefetch slot of tap itap
@@ -915,7 +930,8 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
     for (int i = 0; i < LPB; ++i) dma_b(i, (t0 % R) * S + t0 / R, 0, t0);
     halo_rounds(t0, 1, NSH > 1 ? HBYTES : 0);
   }
-  __syncthreads();                                   // drains the prologue DMA once; zero fill and rowpix visible
+  wait_vmcnt<0>();                                   // the prologue DMA (the compiler does not count the asm ones)
+  __syncthreads();                                   // ... landed for every wave; zero fill and rowpix visible
   VG_STAMP(1);
   if (group == 1 && !VG_DBG(2)) __builtin_amdgcn_s_barrier();     // group 1 runs one barrier behind group 0
 
@@ -979,7 +995,9 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
         if (ph == NPH - 1 && !VG_DBG(2)) wait_vmcnt<(PF - 1) * LPB>();
         if (!VG_DBG(2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifndef VG_EXP_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < KPP; ++kk)
 #pragma unroll
@@ -2298,6 +2316,8 @@ static int conv_fwd_impl(const vg_conv_desc* d, const void* x, const void* w_pac
   int rc = check_desc(d);
   if (rc) return rc;
   VG_REQUIRE(x && w_packed && y, "conv_fwd: null pointer");
+  // every gather-GEMM tile is at least 128 pixels: an upper bound of the blocks that add to one channel's statistics
+  if (stats || bs) VG_DET_GUARD(vg_ceil_div((long)d->n * d->oh * d->ow, 128));
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.det = vg_det_mode();
@@ -2407,6 +2427,7 @@ static int conv_dgrad_impl(const vg_conv_desc* d, const void* dy, const void* w_
   VG_REQUIRE(dy && w_packed_t && dx, "conv_dgrad: null pointer");
   const int s = d->stride;
   VG_REQUIRE(d->h % s == 0 && d->w % s == 0, "conv_dgrad: input %dx%d not a multiple of stride %d", d->h, d->w, s);
+  if (stats || bs) VG_DET_GUARD(vg_ceil_div((long)d->n * d->h * d->w, 128));
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.det = vg_det_mode();
@@ -3139,7 +3160,10 @@ static Wg3Plan wg3_plan(const WgradParams& p, int R, int S, int dtype) {
   q.parts = wg3_groups(pairs, p.N, p.OH, p.OW, th, tw) * (q.kind == 1 && q.ks == 2 ? 1 : q.ks);
   return q;
 }
+static thread_local char g_last_wgrad[48] = "";
+extern "C" const char* vg_last_wgrad_kernel(void) { return g_last_wgrad; }
 static int dispatch_wgrad3(const WgradParams& p, const Wg3Plan& q, hipStream_t st) {
+  snprintf(g_last_wgrad, sizeof g_last_wgrad, "%s<%d,%d,%d>", q.kind == 2 ? "wgrad3s2" : "wgrad3", q.nob, q.ncb, q.ks);
   if (q.kind == 2) {
     if (q.nob == 4) return launch_wgrad3s2<4, 1, 1>(p, st);
     if (q.nob == 2) return launch_wgrad3s2<2, 1, 2>(p, st);
@@ -3238,6 +3262,7 @@ extern "C" int vg_conv_wgrad(const vg_conv_desc* d, const void* x, const void* d
     rc = dispatch_wgrad3(p, q, st);                          // plain stores into q.parts partial images: nothing to clear
   } else {
     VG_HIP(hipMemsetAsync(ws, 0, p.part_elems * sizeof(float), st));
+    snprintf(g_last_wgrad, sizeof g_last_wgrad, "wgrad<%s,per-tap>", d->dtype == VG_BF16 ? "bf16" : "f32");
     rc = d->dtype == VG_BF16 ? dispatch_wgrad<bf16_t>(p, st) : dispatch_wgrad<float>(p, st);
   }
   if (rc) return rc;

@@ -436,12 +436,22 @@ extern "C" int vg_channel_sum_noalloc(const void* a, int64_t rows, int cs, int c
   VG_REQUIRE(cs <= VG_NOALLOC_MAX_CS, "channel_sum_noalloc: channel stride %d exceeds the static scratch (max %d); use "
              "vg_channel_sum with a caller workspace", cs, VG_NOALLOC_MAX_CS);
   const int piece = dtype == VG_BF16 ? 8 : 4;
-  VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_sum_noalloc: channel stride %d unsupported", cs);
+  const bool thin4 = dtype == VG_BF16 && cs == 4;        // the 8-byte-pixel image-side layout, as in vg_channel_sum
+  VG_REQUIRE(thin4 || (cs % piece == 0 && cs / piece <= 256), "channel_sum_noalloc: channel stride %d unsupported", cs);
   double* ws = nullptr;
   int rc = scratch_of_current_device(&ws);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   VG_HIP(hipMemsetAsync(ws, 0, sizeof(double) * cs * VG_STATS_REPLICAS, st));      // the replicas must start at zero
+  if (thin4) {
+    int blocks4 = (int)vg_ceil_div(rows, 256 * 16);
+    if (blocks4 > 2048) blocks4 = 2048;
+    hipLaunchKernelGGL(channel_sum4_kernel, dim3(blocks4), dim3(256), 0, st, (const bf16_t*)a, rows, ws, vg_det_mode());
+    VG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(d2f_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, out, c_valid, 1.0, VG_STATS_REPLICAS, 4, accumulate, vg_det_mode());
+    VG_LAUNCH_CHECK();
+    return VG_OK;
+  }
   const int ppr = cs / piece, rpb = 256 / ppr;
   int blocks = (int)vg_ceil_div(rows, (int64_t)rpb * 16);
   if (blocks > 2048) blocks = 2048;

@@ -633,6 +633,7 @@ extern "C" int vg_thin_conv_fwd(const vg_conv_desc* d, const void* x, const floa
   if (kind == 1) {
     p.thin = (const bf16_t*)x; p.stats = stats; p.cpad = d->co <= 32 ? 32 : 64; p.det = vg_det_mode();
     thin_tiles(p, p.WH, p.WW, 8, 32);
+    if (stats) VG_DET_GUARD(p.ntiles);
     if (d->r == 3) hipLaunchKernelGGL((thin_in_kernel<3, 1>), dim3(p.ntiles), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((thin_in_kernel<4, 2>), dim3(p.ntiles), dim3(256), 0, st, p);
   } else {

@@ -154,6 +154,14 @@ class DeviceLoader:
     def __len__(self):
         return len(self.loader)
 
+    def set_epoch(self, epoch: int) -> None:
+        """Under a DistributedSampler the shuffle is a function of (seed, epoch): without this every epoch of a
+        multi-rank run would walk the shards in the same order, unlike the single-process loader (shuffle=True draws a
+        fresh permutation per epoch, as the reference's does, data.py:133-139)."""
+        sampler = getattr(self.loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+
     def __iter__(self):
         for images in self.loader:
             yield self.transform(images)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "vg_set_conv_kernel": (None, [_I]),
     "vg_set_wgrad_kernel": (None, [_I]),
     "vg_last_conv_kernel": (C.c_char_p, []),
+    "vg_last_wgrad_kernel": (C.c_char_p, []),
     "vg_conv_packed_bytes": (C.c_size_t, [_DP, _I]),
     "vg_conv_pack_weight": (_I, [_DP, _I, _P, _P, _P]),
     "vg_conv_pack_item_bytes": (C.c_size_t, []),
@@ -87,6 +88,8 @@ SIGNATURES = {
     "vg_avgpool2_nchw": (_I, [_P, _P, _L, _I, _I, _P]),
     "vg_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "vg_channel_stats": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "vg_stats_collapse": (_I, [_P, _I, _P, _P]),
+    "vg_stats_load": (_I, [_P, _I, _P, _P]),
     "vg_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "vg_bn_bwd_reduce_dz": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),

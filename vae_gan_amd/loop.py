@@ -128,6 +128,8 @@ def train(model, train_loader, val_loader, config, logger=None, step_fn: Optiona
     best = 0.0
     for epoch in range(config.epochs):
         model.train()
+        if hasattr(train_loader, "set_epoch"):      # multi-rank runs: a fresh shuffle of the shards every epoch
+            train_loader.set_epoch(epoch)
         sums, n, bpps = {}, 0, []
         for i, images in enumerate(train_loader):
             if max_iters is not None and i >= max_iters:

@@ -65,6 +65,8 @@ class KernelProfile:
         e1.record()
         if name is None:      # gather-GEMM launch: ask the library which kernel variant it dispatched
             name = L.load().vg_last_conv_kernel().decode()
+        elif name == "wgrad":   # weight gradient: likewise (the launch also runs the ordered sum / unpack kernel)
+            name = L.load().vg_last_wgrad_kernel().decode() + "+unpack"
         if tag is not None:
             self.tag_kernel[tag] = name
         if self.shapes and tag is not None:
@@ -370,7 +372,7 @@ def _wgrad(desc: L.ConvDesc, x: torch.Tensor, dy: torch.Tensor, wshape, param=No
     ws = torch.empty(lib.vg_conv_wgrad_ws_bytes(C.byref(desc)) // 4, dtype=torch.float32, device=x.device)
     slot = _grad_slot(param)
     dw = slot if slot is not None else torch.empty(wshape, dtype=torch.float32, device=x.device)
-    L.check(_timed("wgrad(memset+wgrad_kernel+unpack)", _conv_flops(desc),
+    L.check(_timed("wgrad", _conv_flops(desc),
                    lambda: lib.vg_conv_wgrad(C.byref(desc), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(),
                                              int(slot is not None), L.stream()), _shape_tag("", desc)), "conv_wgrad")
     return None if slot is not None else dw
@@ -724,7 +726,7 @@ class BNActFn(torch.autograd.Function):
         sync = STAT_SYNC[0]
         count = rows
         if sync is not None:
-            sync.sum_(stats)
+            sync.sum_stats(stats, 2 * cpad)
             count = rows * sync.world
         ctx.count, ctx.sync = count, sync
         L.check(lib.vg_bn_finalize(stats.data_ptr(), c, cpad, count, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
@@ -780,7 +782,7 @@ class BNActFn(torch.autograd.Function):
             bsl.fused = bsl.masked = False
         sync = ctx.sync
         if sync is not None:
-            sync.sum_(sums[:L.STATS_REPLICAS * 2 * cpad])
+            sync.sum_stats(sums[:L.STATS_REPLICAS * 2 * cpad], 2 * cpad)
         dx = torch.empty_like(x)
         if ctx.has_res and dres is None:
             dres = dres_out = torch.empty_like(x)

@@ -64,13 +64,28 @@ class DataParallel:
         if self.world > 1 and bn_sync == "global":
             ops.STAT_SYNC[0] = self
         self.n_async = 0         # buckets that were launched from a backward boundary (tests / diagnostics)
+        self.stat_bytes = 0      # bytes of statistics exchanged (bn_sync='global'): tests hold them to the SURVEY figure
+        self.stat_calls = 0
         # gloo (CPU tests, or several ranks sharing one GPU in the GPU test) moves device tensors through the host
         self._staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     # ---- global-batch statistics (ops.STAT_SYNC interface)
+    def sum_stats(self, stats: torch.Tensor, nslots: int) -> torch.Tensor:
+        """Sum a [replicas][nslots] statistics buffer (BatchNorm forward / backward sums) over the ranks, in place.
+        What travels is ONE f64 per accumulator (``vg_stats_collapse``; nslots = 2 * cpad: the SURVEY section 5 figure
+        of 2 x C values per layer and direction), not the 32 replicas / 22 fixed-point bins it is spread over on the
+        device (32x the bytes in round 2); ``vg_stats_load`` puts the summed vector back in the buffer's own format."""
+        from . import lib as L
+        lib = L.load()
+        vec = torch.empty(nslots, dtype=torch.float64, device=stats.device)
+        L.check(lib.vg_stats_collapse(stats.data_ptr(), nslots, vec.data_ptr(), L.stream()), "stats_collapse")
+        self.sum_(vec)
+        L.check(lib.vg_stats_load(vec.data_ptr(), nslots, stats.data_ptr(), L.stream()), "stats_load")
+        return stats
+
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
-        if t.dtype == torch.float64 and ops.deterministic():
-            t = t.view(torch.int64)      # statistics buffers hold fixed-point bins (vg_api.h: vg_set_deterministic)
+        self.stat_bytes += t.numel() * t.element_size()
+        self.stat_calls += 1
         if self.world > 1:
             if self._staged and t.is_cuda:
                 h = t.cpu()
