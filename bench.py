@@ -196,6 +196,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     finite = bool(torch.isfinite(g_loss["total"]).item() and torch.isfinite(d_loss["total"]).item())
+    # Host cost of a step by itself: one more (untimed) step enqueued into an EMPTY queue.  host_dt above is mostly
+    # back-pressure: with ten steps in flight the launch calls block until the GPU has retired older dispatches (cProfile
+    # with the autograd engine on the calling thread, tests/gpu_host_profile.py: 70 % of it sits inside the launch calls of
+    # the backward pass), so it tracks the GPU's time, not Python's.
+    barrier()
+    t1 = time.perf_counter()
+    vq_train_step(model, images, opt_g, opt_d, dp)
+    host_one = time.perf_counter() - t1
+    barrier()
 
     if rank == 0:
         imgs_per_s = world * args.batch * args.steps / dt
@@ -237,6 +246,8 @@ def main():
             "losses_finite": finite,
             # host time to enqueue a step (rank 0): the margin before the step becomes launch-bound on a slower host
             "host_enqueue_ms_per_step": 1000.0 * host_dt / args.steps,
+            # ... and the same for one step enqueued into an empty queue (no back-pressure): what Python + ctypes cost
+            "host_ms_per_step_empty_queue": 1000.0 * host_one,
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline and args.arch == "vq":

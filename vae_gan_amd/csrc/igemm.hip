@@ -77,13 +77,6 @@ __device__ __forceinline__ int tap_off(unsigned long long pack, int tap) { retur
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   __device__ static inline f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
-#ifdef VG_EXP_MMA16   // timing experiment (make exp EXTRA=-DVG_EXP_MMA16; WRONG results): the same FLOPs as two 16x16x32 MFMAs
-    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c1, 0, 0, 0);
-    for (int i = 0; i < 4; ++i) { c[i] = c0[i]; c[4 + i] = c1[i]; }
-    return c;
-#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
@@ -1480,7 +1473,9 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = pixel-row pair of the tile, or (PH) the phase
-  const int h = lane >> 5, l32 = lane & 31;
+  // v_mfma_f32_16x16x32_bf16 (round 3; the chip holds a higher clock on it than on 32x32x16): lane = row / column m16 of
+  // a 16-wide tile, kb = its 16-byte k slot of the 64-byte channel chunk
+  const int m16 = lane & 15, kb = lane >> 4;
   const int phase = PH ? wave : (int)blockIdx.y;
   const int py = phase / p.out_s, px = phase % p.out_s;
   const int tpi = p.tilesX * p.tilesY;
@@ -1497,20 +1492,18 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
   const unsigned smem0 = lds_addr_of(smem);
 
-  // ---- all weights: registers, once per block.  fb[tap][cc][kk][j]: k = cc*32 + kk*16 + 8h.., channel j*32 + l32
-  u32x4 fb[NTAPS][CCH][2][2];
+  // ---- all weights: registers, once per block.  fb[tap][cc][nt]: k = cc*32 + 8*kb.., channel nt*16 + m16
+  u32x4 fb[NTAPS][CCH][4];
   {
     const size_t ktot = (size_t)NTAPS * p.C;
-    const T* wg = (const T*)p.w + ((size_t)phase * p.Npad + l32) * ktot;
+    const T* wg = (const T*)p.w + ((size_t)phase * p.Npad + m16) * ktot;
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap)
 #pragma unroll
       for (int cc = 0; cc < CCH; ++cc)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            fb[tap][cc][kk][j] = *(const u32x4*)(wg + (size_t)j * 32 * ktot + (size_t)tap * p.C + cc * 32 + (2 * kk + h) * PIECE);
+        for (int nt = 0; nt < 4; ++nt)
+          fb[tap][cc][nt] = *(const u32x4*)(wg + (size_t)nt * 16 * ktot + (size_t)tap * p.C + cc * 32 + kb * PIECE);
   }
   // ---- halo pieces of this thread (the same in every tile): piece q = rd*NT + tid of [CCH][HH*HS pixels][4 slots].
   // The table lives in LDS: 2*HRN more live registers per lane would spill, and a spill reload is a vector memory
@@ -1524,7 +1517,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     const int pix = rem >> 2, ps = rem & 3;
     const int hy = pix / HS, hx = pix - hy * HS;
     const bool ok = q < Cfg::NPIECE && hx < Cfg::WCOLS;
-    ptab[rd * NT] = i32x2{((hy * p.W + hx) * p.Cs) * 2 + cc * 64 + (((ps ^ (hx >> 2)) & 3) << 4), ok ? ((hy << 8) | hx) : -1};
+    ptab[rd * NT] = i32x2{((hy * p.W + hx) * p.Cs) * 2 + cc * 64 + (igemm3_swz<true>(ps, hx) << 4), ok ? ((hy << 8) | hx) : -1};
   }
   // tile k of this block: with the full grid of 256 blocks, the 32 blocks of an XCD (blockIdx % 8) take 32 consecutive tiles
   const bool xcd_order = gridDim.x == 256;
@@ -1535,19 +1528,20 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     const int ty = trem / p.tilesX;
     ty0 = ty * TH; tx0 = (trem - ty * p.tilesX) * TW;
   };
-  // A fragment addresses: column term per horizontal tap (slot of k half 0; ^32 is k half 1); rows are immediates
+  // A fragment addresses: column term per horizontal tap (pixels 0..15 of the row; +1024 = pixels 16..31: the slot swizzle
+  // bit is the same); rows are immediates
   int ct[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int hx = l32 + (flip ? S - 1 - s : s) + coloff;
-    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4) + rowoff * HSB;
+    const int hx = m16 + (flip ? S - 1 - s : s) + coloff;
+    ct[s] = hx * 64 + (igemm3_swz<true>(kb, hx) << 4) + rowoff * HSB;
   }
-  float bv[2];
+  float bv[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    bv[j] = p.bias != nullptr ? p.bias[j * 32 + l32] : 0.f;
+  for (int nt = 0; nt < 4; ++nt) {
+    bv[nt] = p.bias != nullptr ? p.bias[nt * 16 + m16] : 0.f;
   }
-  double st1[2] = {0.0, 0.0}, st2[2] = {0.0, 0.0};
+  double st1[4] = {0.0, 0.0, 0.0, 0.0}, st2[4] = {0.0, 0.0, 0.0, 0.0};
   T* __restrict__ yg = (T*)p.y;
   T* wt = (T*)(smem + Cfg::OFF_STAGE + wave * WTILE);      // [2 rows][32 px][WSTRIDE]
 
@@ -1615,20 +1609,17 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     if (has_next) halo_begin(next);
     __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
     VG_T(0);
-    f32x16 acc[2][2];                  // written by the MFMAs of the first K step (C = 0)
-#ifdef VG_EXP_MMA16
-    f32x4 accq[2][2][2];
-#endif
+    f32x4 acc[2][2][4];                // [pixel row][16-pixel half][16-channel tile]; first written with C = 0
     const unsigned char* hb = smem + buf * HBYTES;
-    // K loop, 36 steps of 4 MFMAs, fully unrolled; the two A fragments of step t+PD are requested before the MFMAs of
-    // step t (one wave per SIMD: nobody else hides the LDS latency)
+    // K loop: 36 steps (tap, channel chunk, 16-pixel half mh = t & 1) of 8 MFMAs (2 rows x 4 channel tiles, all 32 k of
+    // the chunk at once), fully unrolled; the two A fragments of step t+PD are requested before the MFMAs of step t (one
+    // wave per SIMD: nobody else hides the LDS latency)
     constexpr int KSTEPS = CCH * NTAPS * 2;
     static_assert(2 * HRN <= KSTEPS - 8 && ST0 + 18 <= KSTEPS, "halo rounds on the even steps, done well before the loop ends; 8 stores fit");
     auto a_addr = [&](int t) {
-      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, mh = t & 1;
       const int r = tap / S, s = tap % S;
-      const int va0 = ct[s] + cc * CHB + (flip ? R - 1 - r : r) * HSB;
-      return kk ? va0 ^ 32 : va0;
+      return ct[s] + cc * CHB + (flip ? R - 1 - r : r) * HSB + mh * 1024;
     };
     constexpr int PD = VG_IGEMM4_PD;      // prefetch distance in K steps
     constexpr int AFRAGS = 64;
@@ -1646,25 +1637,18 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     // ones: 288 + 64 registers do not fit either file alone.  With the builtin the compiler kept the weights in
     // accumulation registers but copied every fragment into the same four ordinary ones in front of its MFMAs (it never
     // names an accumulation register as a multiplicand), and those copies had to wait for the previous MFMA to read them.
-    auto mfma = [&](int t, int i, int j) {
-      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
-      const bool in_a = ((tap * CCH + cc) * 2 + kk) * 2 + j < AFRAGS;
-      static_assert(AFRAGS >= 2, "the first step's fragments are in accumulation registers");
-#ifdef VG_EXP_MMA16
-      for (int q = 0; q < 2; ++q) {
-        if (t == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(accq[i][j][q]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk][j]));
-        else if (in_a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][j][q]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk][j]));
-        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][j][q]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk][j]));
-      }
-      return;
-#endif
-      if (t == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[i][j]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk][j]));
-      else if (in_a) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk][j]));
-      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk][j]));
+    auto mfma = [&](int t, int i, int nt) {
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, mh = t & 1;
+      const bool in_a = (tap * CCH + cc) * 4 + nt < AFRAGS;
+      static_assert(AFRAGS >= 4, "the first step's fragments are in accumulation registers");
+      if (t < 2) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[i][mh][nt]) : "v"(fa[t][i]), "a"(fb[tap][cc][nt]));
+      else if (in_a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][mh][nt]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][nt]));
+      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][mh][nt]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][nt]));
     };
-    // One K step = 4 MFMAs (32 cycles each; an MFMA holds the wave's issue for 8 of them).  The step's other work is
-    // dealt out over the four gaps so that no gap's issue cost runs far past the MFMA behind it: the two A-fragment
-    // prefetches in the first two, a halo round or a staging read in the third, a deferred store in the fourth.
+    static_assert(PD >= 2, "steps 0 and 1 (the two pixel halves) read fa[0] and fa[1]");
+    // One K step = 8 MFMAs (16 cycles each; an MFMA holds the wave's issue for 8 of them).  The step's other work is
+    // dealt out over the first four gaps: the two A-fragment prefetches in the first two, a halo round or a staging read
+    // in the third, a deferred store in the fourth; the other four gaps stay empty.
 #pragma clang loop unroll(full)
     for (int t = 0; t < KSTEPS; ++t) {
       const int vp = t + PD < KSTEPS ? a_addr(t + PD) : 0;
@@ -1678,6 +1662,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
       if (t + PD < KSTEPS) fa[(t + PD) % (PD + 1)][1] = *(const u32x4*)(hb + vp + HSB);
       __builtin_amdgcn_sched_barrier(0);
       mfma(t, 0, 1);
+      mfma(t, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
       if (t % 2 == 0 && t / 2 < HRN) { if (has_next) halo_round(t / 2, buf ^ 1); }
       if (ACC && t == 1) {
@@ -1688,44 +1673,49 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
       }
       if (t >= ST0 && (t - ST0) % 2 == 1 && (t - ST0) / 2 < 8) { if (has_prev) sreg = stage_piece((t - ST0) / 2); }
       __builtin_amdgcn_sched_barrier(0);
-      mfma(t, 1, 1);
+      mfma(t, 0, 2);
+      mfma(t, 1, 2);
       __builtin_amdgcn_sched_barrier(0);
       if (t >= ST0 + 2 && (t - ST0) % 2 == 0 && (t - ST0 - 2) / 2 < 8) { if (has_prev) store_piece((t - ST0 - 2) / 2, sreg, oreg[(t - ST0 - 2) / 2]); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(t, 0, 3);
+      mfma(t, 1, 3);
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
     __builtin_amdgcn_sched_barrier(0);
-#ifdef VG_EXP_MMA16
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = r < 8 ? accq[i][j][r >> 2][r & 3] : 0.f;
-#endif
     VG_T(1);
     // ---- epilogue (every tile is whole, all 64 channels are real: the launcher's conditions): BatchNorm statistics of
     // the bf16-rounded pre-activation, activation; both pixel rows into the wave's staging tile (stored next tile)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (VG_DBG4(64)) continue;
-      T* wl = wt + i * 32 * WSTRIDE + 4 * h * WSTRIDE + l32;
+      // accumulator (mh, nt), register r = pixel mh*16 + 4*kb + r of row i, channel nt*16 + m16.  The 144-byte staging
+      // rows put the rows 4 apart that a store's 32-lane groups hold (kb, kb + 1) on different banks.
+      T* wl = wt + i * 32 * WSTRIDE + 4 * kb * WSTRIDE + m16;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int nt = 0; nt < 4; ++nt) {
         f32x2 a1 = f32x2{0.f, 0.f}, a2 = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int r2 = 0; r2 < 8; ++r2) {
-          const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2);
-          f32x2 v = f32x2{acc[i][j][r], acc[i][j][r + 1]} + bv[j];
-          bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
-          if (ST || LR) v = __builtin_convertvector(q, f32x2);
-          if (ST) { a1 += v; a2 += v * v; }
-          if (LR) {
-            const f32x2 w = v * VG_LRELU_SLOPE;
-            f32x2 m;
-            asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
-            q = __builtin_convertvector(m, bf16x2_t);
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const int row = mh * 16 + r;
+            f32x2 v = f32x2{acc[i][mh][nt][r], acc[i][mh][nt][r + 1]} + bv[nt];
+            bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+            if (ST || LR) v = __builtin_convertvector(q, f32x2);
+            if (ST) { a1 += v; a2 += v * v; }
+            if (LR) {
+              const f32x2 w = v * VG_LRELU_SLOPE;
+              f32x2 m;
+              asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
+              asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
+              q = __builtin_convertvector(m, bf16x2_t);
+            }
+            wl[row * WSTRIDE + nt * 16] = q[0];
+            wl[(row + 1) * WSTRIDE + nt * 16] = q[1];
           }
-          wl[row * WSTRIDE + j * 32] = q[0];
-          wl[(row + 1) * WSTRIDE + j * 32] = q[1];
-        }
-        if (ST) { st1[j] += (double)(a1[0] + a1[1]); st2[j] += (double)(a2[0] + a2[1]); }
+        if (ST) { st1[nt] += (double)(a1[0] + a1[1]); st2[nt] += (double)(a2[0] + a2[1]); }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1765,9 +1755,10 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     __syncthreads();
     double* red = (double*)(smem + Cfg::OFF_STAGE);      // [4 waves][BN][2]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const double s1 = st1[j] + __shfl_xor(st1[j], 32, 64), s2 = st2[j] + __shfl_xor(st2[j], 32, 64);
-      if (h == 0) { red[(wave * BN + j * 32 + l32) * 2 + 0] = s1; red[(wave * BN + j * 32 + l32) * 2 + 1] = s2; }
+    for (int nt = 0; nt < 4; ++nt) {
+      double s1 = st1[nt] + __shfl_xor(st1[nt], 32, 64), s2 = st2[nt] + __shfl_xor(st2[nt], 32, 64);
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);      // the four k-slot groups hold the same column
+      if (kb == 0) { red[(wave * BN + nt * 16 + m16) * 2 + 0] = s1; red[(wave * BN + nt * 16 + m16) * 2 + 1] = s2; }
     }
     __syncthreads();
     if (tid < BN && tid < p.Nout) {
@@ -1819,7 +1810,7 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = block of 32 output channels
-  const int h = lane >> 5, l32 = lane & 31;
+  const int m16 = lane & 15, kb = lane >> 4;                      // v_mfma_f32_16x16x32_bf16 lane roles (see igemm4)
   const int tpi = p.tilesX * p.tilesY;
   const int dymin = p.dymin_i[0], dxmin = p.dxmin_i[0];
   const bool flip = p.flip != 0;
@@ -1827,18 +1818,18 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
   const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
   const unsigned smem0 = lds_addr_of(smem);
 
-  // ---- this wave's weights: fb[tap][cc][kk]: channel 32*wave + l32, k = cc*32 + kk*16 + 8h..
+  // ---- this wave's weights: fb[tap][cc][nt]: channel 32*wave + 16*nt + m16, k = cc*32 + 8*kb..
   u32x4 fb[NTAPS][CCH][2];
   {
     const size_t ktot = (size_t)NTAPS * p.C;
-    const T* wg = (const T*)p.w + ((size_t)32 * wave + l32) * ktot;
+    const T* wg = (const T*)p.w + ((size_t)32 * wave + m16) * ktot;
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap)
 #pragma unroll
       for (int cc = 0; cc < CCH; ++cc)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-          fb[tap][cc][kk] = *(const u32x4*)(wg + (size_t)tap * p.C + cc * 32 + (2 * kk + h) * PIECE);
+        for (int nt = 0; nt < 2; ++nt)
+          fb[tap][cc][nt] = *(const u32x4*)(wg + (size_t)nt * 16 * ktot + (size_t)tap * p.C + cc * 32 + kb * PIECE);
   }
   // ---- halo piece table: hy | hx << 4 | cc << 10 | source slot << 13 | inside the image columns << 15 | exists << 16
   unsigned* ptab = (unsigned*)(smem + Cfg::OFF_TAB) + tid;
@@ -1848,7 +1839,7 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     const int cc = q / (HH * HS * 4), rem = q - cc * (HH * HS * 4);
     const int pix = rem >> 2, ps = rem & 3;
     const int hy = pix / HS, hx = pix - hy * HS;
-    ptab[rd * NT] = (unsigned)hy | (unsigned)hx << 4 | (unsigned)cc << 10 | (unsigned)((ps ^ (hx >> 2)) & 3) << 13 |
+    ptab[rd * NT] = (unsigned)hy | (unsigned)hx << 4 | (unsigned)cc << 10 | (unsigned)igemm3_swz<true>(ps, hx) << 13 |
                     (unsigned)(hx < TW + S - 1) << 15 | (unsigned)(q < Cfg::NPIECE) << 16;
   }
   const bool xcd_order = gridDim.x == 256;
@@ -1862,11 +1853,13 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
   int ct[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    const int hx = l32 + (flip ? S - 1 - s : s);
-    ct[s] = hx * 64 + (((h ^ (hx >> 2)) & 3) << 4);
+    const int hx = m16 + (flip ? S - 1 - s : s);
+    ct[s] = hx * 64 + (igemm3_swz<true>(kb, hx) << 4);
   }
-  const float bv = p.bias != nullptr ? p.bias[32 * wave + l32] : 0.f;
-  double st1 = 0.0, st2 = 0.0;
+  float bv[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bv[nt] = p.bias != nullptr ? p.bias[32 * wave + 16 * nt + m16] : 0.f;
+  double st1[2] = {0.0, 0.0}, st2[2] = {0.0, 0.0};
   T* __restrict__ yg = (T*)p.y;
   T* wt = (T*)(smem + Cfg::OFF_STAGE + wave * WTILE);      // [4 rows][32 px][32 ch]
 
@@ -1889,7 +1882,7 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
   };
   // deferred stores of the previous tile: piece sidx = row sidx / 2, pixels 16 * (sidx & 1) + lane / 4, 16 bytes lane % 4
   auto stage_piece = [&](int sidx) {
-    return *(const u32x4*)(wt + (sidx >> 1) * 1024 + ((lane + 64 * (sidx & 1)) >> 2) * 32 + (lane & 3) * PIECE);
+    return *(const u32x4*)(wt + (sidx >> 1) * 1024 + ((lane + 64 * (sidx & 1)) >> 2) * 32 + ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * PIECE);
   };
   T* pdst = nullptr;
   auto store_ptr = [&](int sidx) { return pdst + (size_t)(sidx >> 1) * p.OW * BN + (sidx & 1) * 16 * BN; };
@@ -1923,16 +1916,12 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     tile_origin(tile, img, ty0, tx0);
     if (has_next) halo_begin(next);
     __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
-#ifdef VG_EXP_MMA16
-    f32x4 accq[TH][2];
-#endif
-    f32x16 acc[TH];
+    f32x4 acc[TH][2][2];               // [pixel row][16-pixel half mh][16-channel tile nt]
     const unsigned char* hb = smem + buf * HBYTES;
-    auto a_addr = [&](int t) {
-      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
+    auto a_addr = [&](int t) {         // step t = (channel chunk, tap, pixel half mh = t & 1): all 32 k of the chunk
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, mh = t & 1;
       const int r = tap / S, s = tap % S;
-      const int va0 = ct[s] + cc * CHB + (flip ? R - 1 - r : r) * HSB;
-      return kk ? va0 ^ 32 : va0;
+      return ct[s] + cc * CHB + (flip ? R - 1 - r : r) * HSB + mh * 1024;
     };
     constexpr int PD = ACC ? 2 : VG_IGEMM4C_PD, AFRAGS = 64;      // prefetch distance of the A fragments in K steps
     u32x4 fa[PD + 1][TH];
@@ -1946,24 +1935,20 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
 #pragma unroll
       for (int i = 0; i < TH; ++i) fa[t][i] = *(const u32x4*)(hb + va + i * HSB);
     }
-    // One K step = 4 MFMAs (32 cycles each; an MFMA holds the wave's issue for 8 of them).  The step's other work is dealt
-    // out over the four gaps so that no gap's issue cost runs far past the MFMA behind it: A-fragment prefetch in the
-    // first two, a halo round or a staging read in the third, a deferred store in the fourth.
+    // One K step = 8 MFMAs (4 rows x 2 channel tiles, 16 cycles each; an MFMA holds the wave's issue for 8 of them).  The
+    // step's other work is dealt out over the gaps behind each row's pair: A-fragment prefetch behind the first two, a
+    // halo round or a staging read behind the third, a deferred store behind the fourth.
     auto mfma = [&](int t, int i) {
-      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, kk = t & 1;
-      const bool in_a = (tap * CCH + cc) * 2 + kk < AFRAGS;        // 64 fragments in accumulation registers, 8 in ordinary ones
-#ifdef VG_EXP_MMA16
-      for (int q = 0; q < 2; ++q) {
-        if (t == 0) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(accq[i][q]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk]));
-        else if (in_a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][q]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk]));
-        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accq[i][q]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk]));
+      const int cc = t / (NTAPS * 2), tap = (t / 2) % NTAPS, mh = t & 1;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bool in_a = (tap * CCH + cc) * 2 + nt < AFRAGS;      // 64 fragments in accumulation registers, 8 in ordinary ones
+        if (t < 2) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[i][mh][nt]) : "v"(fa[t][i]), "a"(fb[tap][cc][nt]));
+        else if (in_a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][mh][nt]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][nt]));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][mh][nt]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][nt]));
       }
-      return;
-#endif
-      if (t == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc[i]) : "v"(fa[0][i]), "a"(fb[tap][cc][kk]));
-      else if (in_a) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa[t % (PD + 1)][i]), "a"(fb[tap][cc][kk]));
-      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(fa[t % (PD + 1)][i]), "v"(fb[tap][cc][kk]));
     };
+    static_assert(PD >= 2, "steps 0 and 1 (the two pixel halves) read fa[0] and fa[1]");
 #pragma clang loop unroll(full)
     for (int t = 0; t < KSTEPS; ++t) {
       const int vp = t + PD < KSTEPS ? a_addr(t + PD) : 0;
@@ -2000,34 +1985,43 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
     __builtin_amdgcn_sched_barrier(0);
-#ifdef VG_EXP_MMA16
-    for (int i = 0; i < TH; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = r < 8 ? accq[i][r >> 2][r & 3] : 0.f;
-#endif
     // ---- epilogue: statistics of the bf16-rounded pre-activation, activation; the four rows into the staging tile
     {
-      f32x2 a1 = f32x2{0.f, 0.f}, a2 = f32x2{0.f, 0.f};
+      // accumulator (mh, nt), register r = pixel mh*16 + 4*kb + r of row i, channel 16*nt + m16.  The staging rows are 64
+      // bytes: pixels with bit 2 set keep their two 16-channel halves swapped, so that the rows 4 apart held by a store's
+      // 32-lane group (kb, kb + 1) fall on different banks (the deferred-store reads undo it).
+      f32x2 a1[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, a2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
       for (int i = 0; i < TH; ++i) {
-        T* wl = wt + i * 1024 + 4 * h * 32 + l32;
+        T* wlb[2];
 #pragma unroll
-        for (int r2 = 0; r2 < 8; ++r2) {
-          const int r = 2 * r2, row = (r & 3) + 8 * (r >> 2);
-          f32x2 v = f32x2{acc[i][r], acc[i][r + 1]} + bv;
-          bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
-          if (ST || LR) v = __builtin_convertvector(q, f32x2);
-          if (ST) { a1 += v; a2 += v * v; }
-          if (LR) {
-            const f32x2 w = v * VG_LRELU_SLOPE;
-            f32x2 m;
-            asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
-            q = __builtin_convertvector(m, bf16x2_t);
-          }
-          wl[row * 32] = q[0];
-          wl[(row + 1) * 32] = q[1];
-        }
+        for (int nt = 0; nt < 2; ++nt) wlb[nt] = wt + i * 1024 + 4 * kb * 32 + ((nt ^ (kb & 1)) * 16 + m16);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const int row = mh * 16 + r;
+              f32x2 v = f32x2{acc[i][mh][nt][r], acc[i][mh][nt][r + 1]} + bv[nt];
+              bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+              if (ST || LR) v = __builtin_convertvector(q, f32x2);
+              if (ST) { a1[nt] += v; a2[nt] += v * v; }
+              if (LR) {
+                const f32x2 w = v * VG_LRELU_SLOPE;
+                f32x2 m;
+                asm("v_max_f32 %0, %1, %2" : "=v"(m[0]) : "v"(v[0]), "v"(w[0]));
+                asm("v_max_f32 %0, %1, %2" : "=v"(m[1]) : "v"(v[1]), "v"(w[1]));
+                q = __builtin_convertvector(m, bf16x2_t);
+              }
+              wlb[nt][row * 32] = q[0];
+              wlb[nt][(row + 1) * 32] = q[1];
+            }
       }
-      if (ST) { st1 += (double)(a1[0] + a1[1]); st2 += (double)(a2[0] + a2[1]); }
+      if (ST) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { st1[nt] += (double)(a1[nt][0] + a1[nt][1]); st2[nt] += (double)(a2[nt][0] + a2[nt][1]); }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2045,10 +2039,14 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     }
   }
   if (ST) {
-    const double s1 = st1 + __shfl_xor(st1, 32, 64), s2 = st2 + __shfl_xor(st2, 32, 64);
-    if (h == 0) {
-      vg_stats_add(p.stats, p.Npad, 0, 32 * wave + l32, blockIdx.x, s1, p.det);
-      vg_stats_add(p.stats, p.Npad, 1, 32 * wave + l32, blockIdx.x, s2, p.det);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      double s1 = st1[nt] + __shfl_xor(st1[nt], 32, 64), s2 = st2[nt] + __shfl_xor(st2[nt], 32, 64);
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);      // the four k-slot groups hold the same column
+      if (kb == 0) {
+        vg_stats_add(p.stats, p.Npad, 0, 32 * wave + 16 * nt + m16, blockIdx.x, s1, p.det);
+        vg_stats_add(p.stats, p.Npad, 1, 32 * wave + 16 * nt + m16, blockIdx.x, s2, p.det);
+      }
     }
   }
 }
