@@ -445,9 +445,18 @@ def claim_bwdstat(t):
     return lk
 
 
+# Which BatchNorm-backward sums ride in the consumer's input-gradient epilogue.  bit 0: residual BatchNorms (the fused
+# launch also stores the masked gradient: it replaces a pass that reads three tensors and writes one), bit 1: plain ones
+# (replaces a two-tensor read).  Round 3, same box, 20-step pairs: none 38.24 ms, residual only 38.09, plain only 38.47,
+# both 38.34: since the 16x16x32 main loops the epilogue's wait for the BatchNorm input costs more than the two-tensor pass.
+_BNSTAT_FUSION = int(_os.environ.get("VG_BNSTAT_FUSION", "1"))
+
+
 def _dgrad_with_bnstats(prod, final: bool, dtype) -> bool:
-    return (prod is not None and final and prod.claims == 1 and prod.x is not None and dtype == torch.bfloat16
-            and prod.act in (L.ACT_NONE, L.ACT_LRELU) and not _os.environ.get("VG_NO_BNSTAT_FUSION"))
+    if not (prod is not None and final and prod.claims == 1 and prod.x is not None and dtype == torch.bfloat16
+            and prod.act in (L.ACT_NONE, L.ACT_LRELU) and not _os.environ.get("VG_NO_BNSTAT_FUSION")):
+        return False
+    return bool(_BNSTAT_FUSION & (1 if prod.y is not None else 2))
 
 
 def _masked_bn_bwd() -> bool:
