@@ -10,4 +10,4 @@ timeout -s KILL 170 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
 echo mfma done
 timeout -s KILL 170 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pmc_prof -- $B > gpurun_out/pmc_prof.log 2>&1
 echo stats done
-python3 profiles/make_pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/pmc_prof gpurun_out/r02_pmc_traffic_new.json
+python3 profiles/make_pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma gpurun_out/pmc_prof gpurun_out/r03_pmc_traffic_new.json

@@ -1394,7 +1394,12 @@ static int launch_igemm3s2(const IgemmParams& p0, hipStream_t st, bool* handled)
     VG_HIP(vg_lds_attr((const void*)kern, 160 * 1024));                                    \
     hipLaunchKernelGGL(kern, grid, dim3(Cfg::NT), Cfg::LDS, st, p);                        \
   } while (0)
-    if (igemm3_epi(p) == 1) VG_IGEMM3S2_LAUNCH(1); else VG_IGEMM3S2_LAUNCH(0);        // a forward kernel
+    // a forward kernel: a plain convolution (no activation, no statistics: the encoder's downsampling layers) is the forward
+    // instantiation too - the all-features one spills (40 bytes of scratch per lane) and ran them at 570-1000 TFLOP/s
+    const int epi = igemm3_epi(p);
+    if (epi == 1 || (epi == 2 && !p.accumulate)) VG_IGEMM3S2_LAUNCH(1);
+    else if (epi == 3) VG_IGEMM3S2_LAUNCH(3);        // input gradient of a transposed convolution with the fused BatchNorm-backward sums
+    else VG_IGEMM3S2_LAUNCH(0);
 #undef VG_IGEMM3S2_LAUNCH
     VG_LAUNCH_CHECK();
     *handled = true;
@@ -2482,6 +2487,7 @@ struct WgradParams {
   int dbg;              // timing ablations only (VG_ABLATE build): 16 = one B fragment for all taps, 32 = no in-loop DMA, 64 = no barrier
   int det;              // reproducible accumulation (vg_set_deterministic): one pixel split, waves add in order
   size_t part_elems;    // spatial-tile kernels: dw is [groups * KS][part_elems] partial images, written with plain stores
+  int xcd;              // spatial-tile kernels: deal tile ranges to the XCDs (see wg3_walk)
 };
 
 // 64-byte-segment swizzle for [pixel][channel] tiles read through ds_read_b64_tr_b16 (bf16 only)
@@ -2722,6 +2728,35 @@ static int wg3_groups(int pairs, int n, int oh, int ow, int th, int tw) {
   return G > ntiles ? ntiles : G;
 }
 
+// Which tiles a block of the spatial-tile kernels walks.  Plain dealing (xcd == 0): block b is slab pair b % pairs of
+// tile group b / pairs, and group g takes tiles g, g + G, ...  With pairs a multiple of 8 that puts every block of a
+// slab pair on ONE XCD (blocks go to XCD b % 8), so each L2 streams all of dy (or x) for its pairs and HBM sees the
+// tensors once per XCD.  XCD dealing (G a multiple of 8): XCD x = b % 8 owns the contiguous tile range
+// [x * ntiles / 8, (x + 1) * ntiles / 8) and holds G / 8 tile groups with ALL their slab pairs, so the pairs' re-reads
+// of a tile and the halo rows shared by neighbouring tiles hit that XCD's L2 and HBM sees x and dy once.  A single
+// slab pair (64 -> 64 channels) has no re-reads to share and keeps the plain dealing: eight far-apart streams at
+// power-of-two distances measured 4-6 % slower there.
+static int wg3_xcd_dealing() {                         // VG_WG3_XCD=0: plain dealing (A/B runs)
+  static const int v = [] { const char* e = getenv("VG_WG3_XCD"); return e ? atoi(e) : 1; }();
+  return v;
+}
+struct Wg3Walk { int pair, g, t0, step, end; };
+__device__ inline Wg3Walk wg3_walk(int b, int pairs, int G, int ntiles, int xcd) {
+  Wg3Walk w;
+  if (xcd && (G & 7) == 0 && pairs > 1) {
+    const int x = b & 7, k = b >> 3, J = G >> 3;
+    const int j = k / pairs;
+    w.pair = k - j * pairs;
+    w.g = x * J + j;
+    w.t0 = (int)(((long)x * ntiles) >> 3) + j;
+    w.step = J;
+    w.end = (int)(((long)(x + 1) * ntiles) >> 3);
+  } else {
+    w.pair = b % pairs; w.g = b / pairs; w.t0 = w.g; w.step = G; w.end = ntiles;
+  }
+  return w;
+}
+
 template <int NOB, int NCB, int KS>
 struct Wg3Cfg {
   static constexpr int TH = 4, TW = 32, R = 3, S = 3, NTAPS = 9;
@@ -2754,10 +2789,11 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   const int ks = wave % KS, cb = (wave / KS) % NCB, ob = wave / (KS * NCB);
   const int h = lane >> 5, l32 = lane & 31;
   const int pairs = p.otiles * p.ctiles;
-  const int pair = blockIdx.x % pairs, g = blockIdx.x / pairs, G = gridDim.x / pairs;
-  const int o0 = (pair / p.ctiles) * Cfg::BO, c0 = (pair % p.ctiles) * Cfg::BC;
   const int tilesX = (p.OW + TW - 1) / TW, tilesY = (p.OH + TH - 1) / TH;
-  const int tpi = tilesX * tilesY, ntiles = p.N * tpi;
+  const int tpi = tilesX * tilesY;
+  const Wg3Walk walk = wg3_walk(blockIdx.x, pairs, gridDim.x / pairs, p.N * tpi, p.xcd);
+  const int pair = walk.pair, g = walk.g, G = walk.step, ntiles = walk.end;
+  const int o0 = (pair / p.ctiles) * Cfg::BO, c0 = (pair % p.ctiles) * Cfg::BC;
   const int pad = -p.dy_[0];
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
   const unsigned char* __restrict__ dyg = (const unsigned char*)p.dy;
@@ -2826,13 +2862,13 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   const int abase = ob * DYB + ks * TW * 64 + lterm;                 // dy image of this wave's o block, first own row
   const int bbase = NOB * DYB + cb * XB + ks * HS * 64 + lterm;      // x halo image of this wave's c block
 
-  int t = g;
+  int t = walk.t0;
   {
     int img, ty0, tx0;
 #pragma unroll
     for (int pre = 0; pre < NST - 1; ++pre) {
-      if (g + pre * G < ntiles) {
-        tile_pos(g + pre * G, img, ty0, tx0);
+      if (t + pre * G < ntiles) {
+        tile_pos(t + pre * G, img, ty0, tx0);
 #pragma unroll
         for (int r = 0; r < PR; ++r) issue_piece(r, img, ty0, tx0, pre);
       }
@@ -2931,6 +2967,7 @@ static int launch_wgrad3(const WgradParams& p0, hipStream_t st) {
   p.ctiles = (int)vg_ceil_div(p.Cpad, Cfg::BC);
   const int pairs = p.otiles * p.ctiles;
   const int G = wg3_groups(pairs, p.N, p.OH, p.OW, Cfg::TH, Cfg::TW);
+  p.xcd = wg3_xcd_dealing();
   auto kern = wgrad3_kernel<NOB, NCB, KS>;
     VG_HIP(vg_lds_attr((const void*)kern, Cfg::LDS));
   hipLaunchKernelGGL(kern, dim3(pairs * G), dim3(512), Cfg::LDS, st, p);
@@ -2977,10 +3014,11 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   const int ks = (wave >> 1) % KS, cb = (wave / (2 * KS)) % NCB, ob = wave / (2 * KS * NCB);
   const int h = lane >> 5, l32 = lane & 31;
   const int pairs = p.otiles * p.ctiles;
-  const int pair = blockIdx.x % pairs, g = blockIdx.x / pairs, G = gridDim.x / pairs;
-  const int o0 = (pair / p.ctiles) * Cfg::BO, c0 = (pair % p.ctiles) * Cfg::BC;
   const int tilesX = (p.OW + TW - 1) / TW, tilesY = (p.OH + TH - 1) / TH;
-  const int tpi = tilesX * tilesY, ntiles = p.N * tpi;
+  const int tpi = tilesX * tilesY;
+  const Wg3Walk walk = wg3_walk(blockIdx.x, pairs, gridDim.x / pairs, p.N * tpi, p.xcd);
+  const int pair = walk.pair, g = walk.g, G = walk.step, ntiles = walk.end;
+  const int o0 = (pair / p.ctiles) * Cfg::BO, c0 = (pair % p.ctiles) * Cfg::BC;
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
   const unsigned char* __restrict__ dyg = (const unsigned char*)p.dy;
   const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
@@ -3047,13 +3085,13 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   const int abase = ob * DYB + ks * TW * 64 + lterm;
   const int bbase = NOB * DYB + cb * XB + (th * 2 * PLANE + ks * PW) * 64 + lterm;     // planes (a = th, b = 0..1)
 
-  int t = g;
+  int t = walk.t0;
   {
     int img, ty0, tx0;
 #pragma unroll
     for (int pre = 0; pre < 2; ++pre) {
-      if (g + pre * G < ntiles) {
-        tile_pos(g + pre * G, img, ty0, tx0);
+      if (t + pre * G < ntiles) {
+        tile_pos(t + pre * G, img, ty0, tx0);
 #pragma unroll
         for (int r = 0; r < PR; ++r) issue_piece(r, img, ty0, tx0, pre);
       }
@@ -3120,6 +3158,7 @@ static int launch_wgrad3s2(const WgradParams& p0, hipStream_t st) {
   p.ctiles = (int)vg_ceil_div(p.Cpad, Cfg::BC);
   const int pairs = p.otiles * p.ctiles;
   const int G = wg3_groups(pairs, p.N, p.OH, p.OW, Cfg::TH, Cfg::TW);
+  p.xcd = wg3_xcd_dealing();
   auto kern = wgrad3s2_kernel<NOB, NCB, KS>;
     VG_HIP(vg_lds_attr((const void*)kern, Cfg::LDS));
   hipLaunchKernelGGL(kern, dim3(pairs * G), dim3(512), Cfg::LDS, st, p);
