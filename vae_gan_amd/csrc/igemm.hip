@@ -2780,8 +2780,6 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   constexpr int DYP = Cfg::DYP, XP = Cfg::XP, DYB = Cfg::DYB, XB = Cfg::XB, STAGE = Cfg::STAGE, NST = Cfg::NST;
   constexpr int ROWS = TH / KS, KSTEPS = ROWS * 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) bf16x4* tr_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -3004,8 +3002,6 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   constexpr int DYP = Cfg::DYP, XP = Cfg::XP, DYB = Cfg::DYB, XB = Cfg::XB, STAGE = Cfg::STAGE, NST = Cfg::NST;
   constexpr int ROWS = TH / KS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) bf16x4* tr_ptr_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
