@@ -192,6 +192,69 @@ def test_dgrad_bnstats_mask_out_stores_masked_gradient(gpu, case):
     assert float((dg[0] - dg[2]).abs().max() / dg[0].abs().max()) <= 1e-5 and float((dg[1] - dg[3]).abs().max() / dg[1].abs().max()) <= 1e-5
 
 
+# (n, h, w, ci, co, k, stride, pad, mask_out): the launch is a FORWARD gather (the input gradient of a ConvTranspose2d
+# with the desc's ci = the transposed conv's output channels); co = channels of the BatchNorm whose gradient it writes
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 128, 4, 2, 1, 1), (2, 64, 64, 128, 256, 4, 2, 1, 1), (2, 64, 64, 128, 256, 4, 2, 1, 0),
+                                  (2, 32, 32, 256, 512, 4, 2, 1, 1), (3, 50, 54, 64, 128, 4, 2, 1, 0)],
+                         ids=lambda c: "n%d_%dx%d_ci%d_co%d_k%ds%dp%d_mask%d" % c)
+def test_fwd_bnstats_transposed_conv_input_gradient(gpu, case):
+    """vg_conv_fwd_bnstats: the input gradient of a stride-2 ConvTranspose2d is a 4x4 stride-2 forward gather; when it feeds
+    a (residual) BatchNorm's backward the launch takes that BatchNorm's sums and, with mask_out, stores the masked
+    gradient (igemm3s2 with the fused-sums epilogue).  Bits equal to vg_conv_fwd followed by vg_bn_bwd_reduce(_dz)."""
+    import ctypes as C
+    from vae_gan_amd import lib as L
+    n, h, w, ci, co, k, stride, pad, mask_out = case
+    lib = L.load()
+    dt = torch.bfloat16
+    d = G.make_desc(n, h, w, ci, co, k, stride, pad, dt)
+    g = torch.Generator(device="cuda").manual_seed(13)
+    wt = (torch.randn(co, ci, k, k, device="cuda", generator=g) / (ci * k * k) ** 0.5).contiguous()
+    wp = G.pack(lib, d, wt, 0, dt)
+    gy = torch.zeros(n, h, w, d.xcs, device="cuda", dtype=dt)                 # upstream gradient (the gather's input)
+    gy[..., :ci] = torch.randn(n, h, w, ci, device="cuda", generator=g).to(dt)
+    shape = (n, d.oh, d.ow, d.ycs)
+    xraw = torch.zeros(shape, device="cuda", dtype=dt)
+    xraw[..., :co] = torch.randn(n, d.oh, d.ow, co, device="cuda", generator=g).to(dt)
+    ybn = torch.zeros(shape, device="cuda", dtype=dt)
+    ybn[..., :co] = torch.randn(n, d.oh, d.ow, co, device="cuda", generator=g).to(dt)
+    mean, invstd, scale, shift = _bn_vec(co, 0, 6)
+    cpad = 32 if co <= 32 else (64 if co <= 64 else (co + 127) // 128 * 128)
+    rows = n * d.oh * d.ow
+    dx0 = torch.zeros(shape, device="cuda", dtype=dt)
+    L.check(lib.vg_conv_fwd(C.byref(d), gy.data_ptr(), wp.data_ptr(), None, dx0.data_ptr(), None, L.ACT_NONE, 0, L.stream()), "fwd")
+    plain_kernel = lib.vg_last_conv_kernel()
+    want = torch.zeros(L.STATS_REPLICAS * 2 * cpad, dtype=torch.float64, device="cuda")
+    ref = dx0
+    if mask_out:
+        ref = torch.empty_like(dx0)
+        L.check(lib.vg_bn_bwd_reduce_dz(dx0.data_ptr(), ybn.data_ptr(), xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                        scale.data_ptr(), shift.data_ptr(), want.data_ptr(), ref.data_ptr(), rows, d.ycs, co, cpad,
+                                        L.ACT_LRELU, L.VG_BF16, L.stream()), "bn_bwd_reduce_dz")
+    else:
+        L.check(lib.vg_bn_bwd_reduce(dx0.data_ptr(), ybn.data_ptr(), xraw.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                     scale.data_ptr(), shift.data_ptr(), want.data_ptr(), rows, d.ycs, co, cpad, L.ACT_LRELU,
+                                     L.VG_BF16, L.stream()), "bn_bwd_reduce")
+    dx1 = torch.zeros(shape, device="cuda", dtype=dt)
+    got = torch.zeros_like(want)
+    bs = L.BnBwdStats(x=xraw.data_ptr(), y=ybn.data_ptr(), mean=mean.data_ptr(), invstd=invstd.data_ptr(), scale=scale.data_ptr(),
+                      shift=shift.data_ptr(), sums=got.data_ptr(), cpad=cpad, act=L.ACT_LRELU, mask_out=mask_out)
+    fused = C.c_int(-1)
+    L.check(lib.vg_conv_fwd_bnstats(C.byref(d), gy.data_ptr(), wp.data_ptr(), dx1.data_ptr(), 0, C.byref(bs), C.byref(fused),
+                                    L.stream()), "fwd_bnstats")
+    torch.cuda.synchronize()
+    assert lib.vg_last_conv_kernel() == plain_kernel
+    if d.ow >= 24:
+        assert plain_kernel.startswith(b"igemm3s2") and fused.value == 1, (plain_kernel, fused.value)
+    if fused.value == 0:
+        assert torch.equal(dx1, dx0) and float(got.abs().max()) == 0.0
+        return
+    assert torch.equal(dx1, ref)
+    a = want.view(L.STATS_REPLICAS, 2, cpad).sum(0)
+    b = got.view(L.STATS_REPLICAS, 2, cpad).sum(0)
+    scale_ = a.abs().max(dim=1, keepdim=True).values
+    assert float(((a - b).abs() / scale_).max()) <= 2e-6, float(((a - b).abs() / scale_).max())
+
+
 def test_dgrad_bnstats_reports_unfused_kernels(gpu):
     """Kernel variants without the fused sums (f32 parity mode, narrow images) leave the sums alone and say so."""
     import ctypes as C
