@@ -36,4 +36,9 @@ for rows, k, d in [(65536, 8192, 256), (65536, 512, 64), (65536, 4096, 128)]:
         t0 = timeit(lambda: lib.vg_vq_assign(z.data_ptr(), cb.data_ptr(), rows, k, d, idx.data_ptr(), norms.data_ptr(), L.stream()))
         t1 = timeit(lambda: lib.vg_vq_assign_shortlist(z.data_ptr(), cb.data_ptr(), rows, k, d, idx.data_ptr(), ws.data_ptr(),
                                                        flag.data_ptr(), L.stream()))
-        print(f"rows {rows} K {k} D {d} {kind:8s}: exact {t0:8.1f} us   shortlist {t1:8.1f} us   (fallback {int(flag.item())})", flush=True)
+        # candidates per row: the count array of the shortlist workspace (layout of vq_short_layout in csrc/vq.hip)
+        up = lambda v: (v + 255) & ~255
+        off = up(k * 4) + up((k + 31) // 32 * 32 * 4) + up(rows * 4)
+        cnt = ws[off:off + rows * 4].view(torch.int32).float()
+        print(f"rows {rows} K {k} D {d} {kind:8s}: exact {t0:8.1f} us   shortlist {t1:8.1f} us   (fallback {int(flag.item())}; "
+              f"candidates per row: mean {cnt.mean().item():.2f}, max {int(cnt.max().item())})", flush=True)
