@@ -144,8 +144,10 @@ extern "C" int vg_bn_act_fwd(const void* x, const void* res, void* y, const floa
   const int ppr = cs / piece;
   const int64_t np = rows;
   hipStream_t st = (hipStream_t)stream;
-  int nb_fwd = row_blocks(rows, 256 / ppr, 16);
-  if (nb_fwd > 4096) nb_fwd = 4096;
+  static const int fwd_cap = [] { const char* e = getenv("VG_BN_FWD_CAP"); return e ? atoi(e) : 16384; }();
+  static const int fwd_rpt = [] { const char* e = getenv("VG_BN_FWD_RPT"); return e ? atoi(e) : 4; }();
+  int nb_fwd = row_blocks(rows, 256 / ppr, fwd_rpt);
+  if (nb_fwd > fwd_cap) nb_fwd = fwd_cap;
   dim3 g(nb_fwd), b(256);
 #define VG_BN_FWD(T, R, A)                                                                                                  \
   hipLaunchKernelGGL((bn_act_fwd_kernel<T, R, A>), g, b, 0, st, (const T*)x, (const T*)res, (T*)y, scale, shift, np, ppr, c, act)
@@ -272,8 +274,10 @@ static int bn_bwd_reduce_launch(const void* dout, const void* y, const void* x, 
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "bn_bwd_reduce: channel stride %d unsupported", cs);
   const int rpb = 256 / (cs / piece);
-  int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 16);
-  if (blocks > 2048) blocks = 2048;
+  static const int red_cap = [] { const char* e = getenv("VG_BN_RED_CAP"); return e ? atoi(e) : 2048; }();
+  static const int red_rpt = [] { const char* e = getenv("VG_BN_RED_RPT"); return e ? atoi(e) : 16; }();
+  int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * red_rpt);
+  if (blocks > red_cap) blocks = red_cap;
   hipStream_t st = (hipStream_t)stream;
   if (y == nullptr && !xmask) y = x;    // no activation: the value is never looked at
   const int det = vg_det_mode();
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     if (HAS_DRES) *(decltype(rd.v)*)(dres + off) = rd.v;
   };
   if (rr < rpb) {
-    constexpr int U = 2;                                   // rows in flight per thread
+    constexpr int U = 2;                                   // rows in flight per thread (4: -3 % at 64 channels, +5..12 % at 256 / 512)
     const int64_t stride = rpb;                            // a block walks its own contiguous chunk of rows
     const int64_t chunk = (((rows + gridDim.x - 1) / gridDim.x + rpb * U - 1) / (rpb * U)) * (rpb * U);
     const int64_t rend = min(rows, (int64_t)(blockIdx.x + 1) * chunk);
@@ -446,8 +450,13 @@ extern "C" int vg_bn_bwd_apply(const void* dout, const void* y, const void* x, c
   if (closed) dxsum = nullptr;
   const int ppr = cs / piece;
   const int64_t np = rows;
-  int nblocks = row_blocks(rows, 256 / ppr, 16);               // >= 16 rows per thread: the coefficient preamble amortises
-  if (nblocks > 2048) nblocks = 2048;
+  // Grid: many short blocks.  Round 2 ran <= 2048 blocks of >= 16 rows per thread (sized for the per-block bias-sum atomics
+  // that most launches no longer have); 16384 blocks of >= 4 rows are 3-10 % faster per launch at 64-256 channels, as a plain
+  // copy is (tests/micro/stream_bw.hip), and 0.3 ms per step (scripts/bn_blocks_step_ab.sh).  VG_BN_*_CAP / _RPT: A/B only.
+  static const int apply_cap = [] { const char* e = getenv("VG_BN_APPLY_CAP"); return e ? atoi(e) : 16384; }();
+  static const int apply_rpt = [] { const char* e = getenv("VG_BN_APPLY_RPT"); return e ? atoi(e) : 4; }();
+  int nblocks = row_blocks(rows, 256 / ppr, apply_rpt);               // >= 16 rows per thread: the coefficient preamble amortises
+  if (nblocks > apply_cap) nblocks = apply_cap;
   if (dxsum != nullptr) {                                      // every block ends with c same-address f32 atomics
     const int cap = 262144 / c < 256 ? 256 : 262144 / c;        // <= 256 K atomics per launch (c = 512: 56 -> 48 us)
     if (nblocks > cap) nblocks = cap;
@@ -577,8 +586,10 @@ extern "C" int vg_channel_stats(const void* x, double* stats, int64_t rows, int 
   const int piece = dtype == VG_BF16 ? 8 : 4;
   VG_REQUIRE(cs % piece == 0 && cs / piece <= 256, "channel_stats: channel stride %d unsupported", cs);
   const int rpb = 256 / (cs / piece);
-  int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * 16);
-  if (blocks > 2048) blocks = 2048;
+  static const int red_cap = [] { const char* e = getenv("VG_BN_RED_CAP"); return e ? atoi(e) : 2048; }();
+  static const int red_rpt = [] { const char* e = getenv("VG_BN_RED_RPT"); return e ? atoi(e) : 16; }();
+  int64_t blocks = vg_ceil_div(rows, (int64_t)rpb * red_rpt);
+  if (blocks > red_cap) blocks = red_cap;
   if (dtype == VG_BF16) hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, stats, rows, cs, c, cpad, vg_det_mode());
   else hipLaunchKernelGGL(channel_stats_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, stats, rows, cs, c, cpad, vg_det_mode());
   VG_LAUNCH_CHECK();
