@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const
         cnt = 0;
       }
     };
-    constexpr int U = 2;                                 // rows in flight per thread
+    constexpr int U = 4;                                 // rows in flight per thread
     const int64_t stride = rpb;                          // a block walks its own contiguous chunk of rows
     const int64_t chunk = (((rows + gridDim.x - 1) / gridDim.x + rpb * U - 1) / (rpb * U)) * (rpb * U);
     const int64_t rend = min(rows, (int64_t)(blockIdx.x + 1) * chunk);
