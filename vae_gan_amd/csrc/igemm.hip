@@ -145,6 +145,25 @@ __device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, un
                : "s"(lds_byte_off), "v"(voff), "s"(sbase)
                : "memory");
 }
+// LDS-DMA through a buffer resource, for the one-wave-per-SIMD kernels, where every instruction between two MFMAs counts.
+// A lane whose offset is outside the resource's range gets ZEROS written to its LDS slot (tests/micro/buf_lds.hip), so an
+// out-of-image halo piece needs no address select against a block of zeros: its offset is replaced by 0xFFFFFFFF (one
+// v_cndmask with an inline constant instead of a 64-bit add and a 64-bit select).  M0 is written and not restored: the
+// compiler treats it as reserved and neither reads nor writes it in these kernels (checked in the ISA:
+// scripts/check_m0.py); a kernel that mixes this with builtins that use M0 must save and restore it as lds_dma16 does.
+typedef int vg_srd_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ vg_srd_t vg_make_srd(const void* base) {       // raw buffer: stride 0, 2 GB of records
+  const unsigned long long b = (unsigned long long)base;
+  vg_srd_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xFFFFFFFFull));
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xFFFFull));
+  r[2] = (int)0x80000000u;
+  r[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void lds_dma16_buf(vg_srd_t srd, unsigned voff, unsigned lds_byte_off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_byte_off), "v"(voff), "s"(srd) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
@@ -1443,6 +1462,9 @@ static bool g_conv_kernel_is_old() { return g_conv_kernel < 3; }
 #ifndef VG_IGEMM4_PD
 #define VG_IGEMM4_PD 2
 #endif
+#ifndef VG_HALO_SPLIT
+#define VG_HALO_SPLIT 1
+#endif
 // PH ("a phase per wave"): stride-2 transposed gathers (transposed convolutions, input gradients of stride-2
 // convolutions) = four output phases (py, px) of 2x2 taps over the same input pixels.  The four waves of a block take
 // one phase each, with that phase's 2x2 x C x 64 weights in registers, over the SAME 2 x 32 input pixel tile: one halo
@@ -1494,7 +1516,6 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   const int coloff = p.dxmin_i[phase] - dxmin;
   const bool flip = p.flip != 0;
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
-  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
   const unsigned smem0 = lds_addr_of(smem);
 
   // ---- all weights: registers, once per block.  fb[tap][cc][nt]: k = cc*32 + 8*kb.., channel nt*16 + m16
@@ -1553,20 +1574,31 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   // One halo round of tile `tile` into buffer `buf`: every lane issues (padding pieces fetch zeros into the buffer's
   // padding), so a wave's DMA count per tile is always HRN.  `e` is this round's table entry, read a round ahead.
   i32x2 e = ptab[0];
-  const unsigned char* hbase = nullptr;       // origin pixel of the tile being fetched
+  vg_srd_t hsrd = vg_make_srd(xg);            // buffer resource at the origin pixel of the tile being fetched
   int hiy0 = 0, hix0 = 0;
   auto halo_begin = [&](int tile) {
     int img, ty0, tx0;
     tile_origin(tile, img, ty0, tx0);
     hiy0 = ty0 + dymin; hix0 = tx0 + dxmin;
-    hbase = xg + ((long)((long)img * p.H + hiy0) * p.W + hix0) * p.Cs * 2;
+    hsrd = vg_make_srd(xg + ((long)((long)img * p.H + hiy0) * p.W + hix0) * p.Cs * 2);
   };
-  auto halo_round = [&](int rd, int buf) {
+  // A halo round is dealt out over two MFMA gaps of the K loop (bounds test and offset select | DMA issue + next table
+  // entry): one wave per SIMD hides ~6 instructions behind a pair of MFMAs, and the round as one block stalled the matrix
+  // pipe for the rest (43 instructions with the short-circuit && of round 2, which compiled to nested divergent branches
+  // around a 64-bit select against the block of zeros; 13 now, through a buffer resource: lds_dma16_buf).  The empty asm
+  // statement pins the first part to the gap it is written in.
+  unsigned h_off = 0xFFFFFFFFu;
+  auto halo_a = [&]() {
     const int hy = e.y >> 8, hx = e.y & 255;
-    const bool in = e.y >= 0 && (unsigned)(hiy0 + hy) < (unsigned)p.H && (unsigned)(hix0 + hx) < (unsigned)p.W;
-    lds_dma16(in ? hbase + e.x : zsrc, smem0 + buf * HBYTES + (rd * NT + wave * 64) * 16);
+    const bool in = (e.y >= 0) & ((unsigned)(hiy0 + hy) < (unsigned)p.H) & ((unsigned)(hix0 + hx) < (unsigned)p.W);      // no short-circuit
+    h_off = in ? (unsigned)e.x : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(h_off));
+  };
+  auto halo_c = [&](int rd, int buf) {
+    lds_dma16_buf(hsrd, h_off, smem0 + buf * HBYTES + (rd * NT + wave * 64) * 16);
     e = ptab[(rd + 1 == HRN ? 0 : rd + 1) * NT];
   };
+  auto halo_round = [&](int rd, int buf) { halo_a(); halo_c(rd, buf); };      // the prologue's rounds
   // The output rows of a tile go to memory during the K loop of the NEXT tile, one 1 KB store every other step, and
   // the halo of the next tile arrives the same way: a block that issued its loads and stores in bursts stalled at
   // issue (the memory queues of a CU are short) with the matrix cores idle, and since every block runs the same
@@ -1608,10 +1640,12 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   int buf = 0;
   for (int k = 0; tile < p.mtiles; ++k, buf ^= 1) {
     const int next = tile_of(k + 1);
-    const bool has_next = next < p.mtiles && !VG_DBG4(1);
+    // The halo rounds of the K loop are unconditional (a uniform `has_next` test cost four instructions and a branch in
+    // front of every round): the block's last tile fetches its own halo again, into the buffer nobody reads.
+    const bool has_next = next < p.mtiles;
     int img, ty0, tx0;
     tile_origin(tile, img, ty0, tx0);
-    if (has_next) halo_begin(next);
+    halo_begin(has_next ? next : tile);
     __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
     VG_T(0);
     f32x4 acc[2][2][4];                // [pixel row][16-pixel half][16-channel tile]; first written with C = 0
@@ -1669,7 +1703,8 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
       mfma(t, 0, 1);
       mfma(t, 1, 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (t % 2 == 0 && t / 2 < HRN) { if (has_next) halo_round(t / 2, buf ^ 1); }
+      if (VG_HALO_SPLIT) { if (t % 2 == 0 && t / 2 < HRN && !VG_DBG4(1)) halo_a(); }
+      else if (t % 2 == 0 && t / 2 < HRN && !VG_DBG4(1)) halo_round(t / 2, buf ^ 1);
       if (ACC && t == 1) {
         if (has_prev) {
 #pragma unroll
@@ -1682,6 +1717,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
       mfma(t, 1, 2);
       __builtin_amdgcn_sched_barrier(0);
       if (t >= ST0 + 2 && (t - ST0) % 2 == 0 && (t - ST0 - 2) / 2 < 8) { if (has_prev) store_piece((t - ST0 - 2) / 2, sreg, oreg[(t - ST0 - 2) / 2]); }
+      if (VG_HALO_SPLIT && t % 2 == 1 && t / 2 < HRN && !VG_DBG4(1)) halo_c(t / 2, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma(t, 0, 3);
       mfma(t, 1, 3);
@@ -1732,8 +1768,8 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     // at the top of the next iteration mean "the next halo is in LDS"
     VG_T(2);
     {
-      // stores issued after the last halo round (K step 2*HRN-2): they may stay in flight
-      constexpr int LATE = [] { int n = 0; for (int s_ = 0; s_ < 8; ++s_) n += ST0 + 2 + 2 * s_ >= 2 * HRN - 2; return n; }();
+      // stores issued after the last halo round (K step 2*HRN-1): they may stay in flight
+      constexpr int LATE = [] { int n = 0; for (int s_ = 0; s_ < 8; ++s_) n += ST0 + 2 + 2 * s_ >= 2 * HRN; return n; }();      // (a lower bound without the split)      // the last DMA goes out in step 2 * HRN - 1
       if (ACC && has_prev && VG_ABLATE_LEVEL < 2) wait_vmcnt<LATE>(); else wait_vmcnt<0>();
     }
     VG_T(3);
@@ -1820,7 +1856,6 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
   const int dymin = p.dymin_i[0], dxmin = p.dxmin_i[0];
   const bool flip = p.flip != 0;
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
-  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
   const unsigned smem0 = lds_addr_of(smem);
 
   // ---- this wave's weights: fb[tap][cc][nt]: channel 32*wave + 16*nt + m16, k = cc*32 + 8*kb..
@@ -1836,16 +1871,23 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
         for (int nt = 0; nt < 2; ++nt)
           fb[tap][cc][nt] = *(const u32x4*)(wg + (size_t)nt * 16 * ktot + (size_t)tap * p.C + cc * 32 + kb * PIECE);
   }
-  // ---- halo piece table: hy | hx << 4 | cc << 10 | source slot << 13 | inside the image columns << 15 | exists << 16
+  // ---- halo piece table, 4 bytes per entry (two 54 KB halo images leave no room for more): byte offset of the piece from
+  // the halo's origin pixel (21 bits: the launcher checks HH * W * Cs * 2 < 2^21) | hy << 21 | hx << 24 | inside the image
+  // columns << 30 | exists << 31.  (Round 2 packed (hy, hx, chunk, slot) and rebuilt the offset with two 32-bit multiplies
+  // per round: 52 instructions between two MFMAs for every halo round, a quarter of the K loop.)
   unsigned* ptab = (unsigned*)(smem + Cfg::OFF_TAB) + tid;
+  {
+    const int wcs2 = p.W * p.Cs * 2, cs2 = p.Cs * 2;
 #pragma unroll
-  for (int rd = 0; rd < HRN; ++rd) {
-    const int q = rd * NT + tid;
-    const int cc = q / (HH * HS * 4), rem = q - cc * (HH * HS * 4);
-    const int pix = rem >> 2, ps = rem & 3;
-    const int hy = pix / HS, hx = pix - hy * HS;
-    ptab[rd * NT] = (unsigned)hy | (unsigned)hx << 4 | (unsigned)cc << 10 | (unsigned)igemm3_swz<true>(ps, hx) << 13 |
-                    (unsigned)(hx < TW + S - 1) << 15 | (unsigned)(q < Cfg::NPIECE) << 16;
+    for (int rd = 0; rd < HRN; ++rd) {
+      const int q = rd * NT + tid;
+      const int cc = q / (HH * HS * 4), rem = q - cc * (HH * HS * 4);
+      const int pix = rem >> 2, ps = rem & 3;
+      const int hy = pix / HS, hx = pix - hy * HS;
+      const unsigned off = (unsigned)(hy * wcs2 + hx * cs2 + cc * 64 + igemm3_swz<true>(ps, hx) * 16) & 0x1FFFFFu;
+      ptab[rd * NT] = off | (unsigned)hy << 21 | (unsigned)hx << 24 | (unsigned)(hx < TW + S - 1) << 30 |
+                      (unsigned)(q < Cfg::NPIECE) << 31;
+    }
   }
   const bool xcd_order = gridDim.x == 256;
   auto tile_of = [&](int k) { return xcd_order ? ((k * 8 + (int)(blockIdx.x & 7)) * 32 + (int)(blockIdx.x >> 3)) : k * (int)gridDim.x + (int)blockIdx.x; };
@@ -1869,22 +1911,28 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
   T* wt = (T*)(smem + Cfg::OFF_STAGE + wave * WTILE);      // [4 rows][32 px][32 ch]
 
   unsigned e = ptab[0];
-  const unsigned char* hbase = nullptr;
+  vg_srd_t hsrd = vg_make_srd(xg);
   int hiy0 = 0, hix0 = 0;
   auto halo_begin = [&](int tile) {
     int img, ty0, tx0;
     tile_origin(tile, img, ty0, tx0);
     hiy0 = ty0 + dymin; hix0 = tx0 + dxmin;
-    hbase = xg + ((long)((long)img * p.H + hiy0) * p.W + hix0) * p.Cs * 2;
+    hsrd = vg_make_srd(xg + ((long)((long)img * p.H + hiy0) * p.W + hix0) * p.Cs * 2);
   };
-  const int wcs2 = p.W * p.Cs * 2, cs2 = p.Cs * 2;
-  auto halo_round = [&](int rd, int buf) {
-    const int hy = e & 15, hx = (e >> 4) & 63;
-    const bool in = (e >> 15 & 1) && (unsigned)(hiy0 + hy) < (unsigned)p.H && (unsigned)(hix0 + hx) < (unsigned)p.W;
-    const int off = hy * wcs2 + hx * cs2 + (int)((e >> 10 & 7) * 64 + (e >> 13 & 3) * 16);
-    if (e >> 16 & 1) lds_dma16(in ? hbase + off : zsrc, smem0 + buf * HBYTES + (rd * NT + wave * 64) * 16);
+  // two parts over two MFMA gaps, through a buffer resource: see igemm4
+  unsigned h_off = 0xFFFFFFFFu;
+  auto halo_a = [&]() {
+    const int hy = (e >> 21) & 7, hx = (e >> 24) & 63;
+    const bool in = ((e >> 30 & 1) != 0) & ((unsigned)(hiy0 + hy) < (unsigned)p.H) & ((unsigned)(hix0 + hx) < (unsigned)p.W);
+    h_off = in ? (e & 0x1FFFFFu) : 0xFFFFFFFFu;
+    asm volatile("" : "+v"(h_off));
+  };
+  auto halo_c = [&](int rd, int buf) {
+    // only the last round has lanes past the image's end; they must not write, not even zeros: the buffers are exact
+    if (rd + 1 < HRN || (int)e < 0) lds_dma16_buf(hsrd, h_off, smem0 + buf * HBYTES + (rd * NT + wave * 64) * 16);
     e = ptab[(rd + 1 == HRN ? 0 : rd + 1) * NT];
   };
+  auto halo_round = [&](int rd, int buf) { halo_a(); halo_c(rd, buf); };      // the prologue's rounds
   // deferred stores of the previous tile: piece sidx = row sidx / 2, pixels 16 * (sidx & 1) + lane / 4, 16 bytes lane % 4
   auto stage_piece = [&](int sidx) {
     return *(const u32x4*)(wt + (sidx >> 1) * 1024 + ((lane + 64 * (sidx & 1)) >> 2) * 32 + ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * PIECE);
@@ -1919,7 +1967,7 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     const bool has_next = next < p.mtiles;
     int img, ty0, tx0;
     tile_origin(tile, img, ty0, tx0);
-    if (has_next) halo_begin(next);
+    halo_begin(has_next ? next : tile);      // unconditional halo rounds: see igemm4
     __syncthreads();                   // halo(tile) has landed for every wave; nobody reads the other buffer any more
     f32x4 acc[TH][2][2];               // [pixel row][16-pixel half mh][16-channel tile nt]
     const unsigned char* hb = smem + buf * HBYTES;
@@ -1974,7 +2022,8 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mfma(t, 2);
       __builtin_amdgcn_sched_barrier(0);
-      if (t % 2 == 0 && t / 2 < HRN) { if (has_next) halo_round(t / 2, buf ^ 1); }
+      if (VG_HALO_SPLIT) { if (t % 2 == 0 && t / 2 < HRN) halo_a(); }
+      else if (t % 2 == 0 && t / 2 < HRN) halo_round(t / 2, buf ^ 1);
       if (ACC && t == 1) {
         if (has_prev) {
 #pragma unroll
@@ -1986,6 +2035,7 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
       mfma(t, 3);
       __builtin_amdgcn_sched_barrier(0);
       if (t >= ST0 + 2 && (t - ST0) % 2 == 0 && (t - ST0 - 2) / 2 < NST) { if (has_prev) store_piece((t - ST0 - 2) / 2, sreg, oreg[(t - ST0 - 2) / 2]); }
+      if (VG_HALO_SPLIT && t % 2 == 1 && t / 2 < HRN) halo_c(t / 2, buf ^ 1);
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 15\n\ts_nop 15");     // MFMA result -> VALU / LDS read (no hazard recognizer for inline MFMAs)
@@ -2130,6 +2180,7 @@ static int launch_igemm4c(const IgemmParams& p0, hipStream_t st, bool* handled) 
   if (!asc && !desc) return VG_OK;
   p.flip = asc ? 0 : 1;
   if ((size_t)p.H * p.W * p.Cs * 2 >= ((size_t)1 << 31)) return VG_OK;
+  if ((size_t)Cfg::HH * p.W * p.Cs * 2 >= ((size_t)1 << 21)) return VG_OK;    // 21-bit piece offsets in the packed halo table
   p.tilesX = p.OWl / Cfg::TW;
   p.tilesY = p.OHl / Cfg::TH;
   p.mtiles = p.N * p.tilesX * p.tilesY;
