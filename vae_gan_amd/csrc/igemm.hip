@@ -2846,7 +2846,6 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   const int pad = -p.dy_[0];
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
   const unsigned char* __restrict__ dyg = (const unsigned char*)p.dy;
-  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
 
   // ---- DMA pieces of this wave: round r moves piece u = r*8 + wave (wrapped: the spare slots of the last
   // round repeat early pieces, same bytes to the same place, so every wave issues exactly PR per tile)
@@ -2883,20 +2882,27 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
     const int ty = rem / tilesX;
     ty0 = ty * TH; tx0 = (rem - ty * tilesX) * TW;
   };
-  auto issue_piece = [&](int r, int img, int ty0, int tx0, int stage) {
+  // One piece = ~18 instructions, half of them scalar: the tile's two origins are buffer resources, a lane outside its
+  // image (or in the padding of the piece grid: row 0x4000) gets offset 0xFFFFFFFF and the DMA writes zeros for it
+  // (lds_dma16_buf).  Round 2 selected between a 64-bit address and a block of zeros behind wave-uniform and divergent
+  // branches: 36 instructions per piece, 8 pieces per wave and tile.
+  struct TileSrc { vg_srd_t dy, x; int ty0, tx0; };      // the two origins of a tile as buffer resources (once per tile)
+  auto tile_src = [&](int img, int ty0, int tx0) {
+    TileSrc ts;
+    ts.dy = vg_make_srd(dyg + ((size_t)((size_t)img * p.OH + ty0) * p.OW + tx0) * p.Os * 2);
+    ts.x = vg_make_srd(xg + ((long)((long)img * p.H + ty0 - pad) * p.W + tx0 - pad) * p.Cs * 2);
+    ts.ty0 = ty0; ts.tx0 = tx0;
+    return ts;
+  };
+  auto issue_piece = [&](int r, const TileSrc& ts, int stage) {
     const int ly = pyx[r] >> 16, lx = pyx[r] & 0xffff;
-    const unsigned char* src;
-    if (pisdy[r]) {
-      const bool ok = ty0 + ly < p.OH && tx0 + lx < p.OW;
-      const unsigned char* base = dyg + ((size_t)((size_t)img * p.OH + ty0) * p.OW + tx0) * p.Os * 2;
-      src = ok ? base + poff[r] : zsrc;
-    } else {
-      const int iy = ty0 - pad + ly, ix = tx0 - pad + lx;
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned char* base = xg + ((long)((long)img * p.H + ty0 - pad) * p.W + tx0 - pad) * p.Cs * 2;
-      src = ok ? base + poff[r] : zsrc;
-    }
-    lds_dma16(src, smem_base + (unsigned)(stage * STAGE + pdst[r]));
+    const bool isdy = pisdy[r];                              // wave-uniform
+    const int oy = isdy ? ts.ty0 : ts.ty0 - pad, ox = isdy ? ts.tx0 : ts.tx0 - pad;
+    const unsigned limy = isdy ? (unsigned)p.OH : (unsigned)p.H, limx = isdy ? (unsigned)p.OW : (unsigned)p.W;
+    const bool ok = ((unsigned)(oy + ly) < limy) & ((unsigned)(ox + lx) < limx);
+    vg_srd_t srd = ts.x;
+    if (isdy) srd = ts.dy;
+    lds_dma16_buf(srd, ok ? poff[r] : 0xFFFFFFFFu, smem_base + (unsigned)(stage * STAGE + pdst[r]));
   };
 
   f32x16 acc[NTAPS];
@@ -2918,8 +2924,9 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
     for (int pre = 0; pre < NST - 1; ++pre) {
       if (t + pre * G < ntiles) {
         tile_pos(t + pre * G, img, ty0, tx0);
+        const TileSrc ts = tile_src(img, ty0, tx0);
 #pragma unroll
-        for (int r = 0; r < PR; ++r) issue_piece(r, img, ty0, tx0, pre);
+        for (int r = 0; r < PR; ++r) issue_piece(r, ts, pre);
       }
     }
   }
@@ -2940,8 +2947,9 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
     // prefetch of tile t+2G, all of it before the tile's own work: the stream is latency-bound, and the earlier the
     // pieces are in flight the better (spread over the k steps: 0.484 ms, all at once: 0.407 ms on 64->64@256^2)
     if (more && !VG_DBG(32)) {
+      const TileSrc ts = tile_src(nimg, nty0, ntx0);
 #pragma unroll
-      for (int r = 0; r < PR; ++r) issue_piece(r, nimg, nty0, ntx0, nstage);
+      for (int r = 0; r < PR; ++r) issue_piece(r, ts, nstage);
     }
 #pragma unroll
     for (int kstep = 0; kstep < KSTEPS; ++kstep) {
@@ -3068,7 +3076,6 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   const int o0 = (pair / p.ctiles) * Cfg::BO, c0 = (pair % p.ctiles) * Cfg::BC;
   const unsigned char* __restrict__ xg = (const unsigned char*)p.x;
   const unsigned char* __restrict__ dyg = (const unsigned char*)p.dy;
-  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
 
   const unsigned smem_base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr_of(smem));
   unsigned poff[PR];        // dy: from pixel (ty0, tx0); x: from input pixel (2*ty0 - 1, 2*tx0 - 1)
@@ -3105,20 +3112,23 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
     const int ty = rem / tilesX;
     ty0 = ty * TH; tx0 = (rem - ty * tilesX) * TW;
   };
-  auto issue_piece = [&](int r, int img, int ty0, int tx0, int stage) {
+  struct TileSrc { vg_srd_t dy, x; int ty0, tx0; };      // the two origins of a tile as buffer resources (once per tile)
+  auto tile_src = [&](int img, int ty0, int tx0) {
+    TileSrc ts;
+    ts.dy = vg_make_srd(dyg + ((size_t)((size_t)img * p.OH + ty0) * p.OW + tx0) * p.Os * 2);
+    ts.x = vg_make_srd(xg + ((long)((long)img * p.H + 2 * ty0 - 1) * p.W + 2 * tx0 - 1) * p.Cs * 2);
+    ts.ty0 = ty0; ts.tx0 = tx0;
+    return ts;
+  };
+  auto issue_piece = [&](int r, const TileSrc& ts, int stage) {
     const int ly = pyx[r] >> 16, lx = pyx[r] & 0xffff;
-    const unsigned char* src;
-    if (pisdy[r]) {
-      const bool ok = ty0 + ly < p.OH && tx0 + lx < p.OW;
-      const unsigned char* base = dyg + ((size_t)((size_t)img * p.OH + ty0) * p.OW + tx0) * p.Os * 2;
-      src = ok ? base + poff[r] : zsrc;
-    } else {
-      const int iy = 2 * ty0 - 1 + ly, ix = 2 * tx0 - 1 + lx;
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const unsigned char* base = xg + ((long)((long)img * p.H + 2 * ty0 - 1) * p.W + 2 * tx0 - 1) * p.Cs * 2;
-      src = ok ? base + poff[r] : zsrc;
-    }
-    lds_dma16(src, smem_base + (unsigned)(stage * STAGE + pdst[r]));
+    const bool isdy = pisdy[r];                              // wave-uniform
+    const int oy = isdy ? ts.ty0 : 2 * ts.ty0 - 1, ox = isdy ? ts.tx0 : 2 * ts.tx0 - 1;
+    const unsigned limy = isdy ? (unsigned)p.OH : (unsigned)p.H, limx = isdy ? (unsigned)p.OW : (unsigned)p.W;
+    const bool ok = ((unsigned)(oy + ly) < limy) & ((unsigned)(ox + lx) < limx);
+    vg_srd_t srd = ts.x;
+    if (isdy) srd = ts.dy;
+    lds_dma16_buf(srd, ok ? poff[r] : 0xFFFFFFFFu, smem_base + (unsigned)(stage * STAGE + pdst[r]));
   };
 
   f32x16 acc[8];            // local tap lt = u*4 + s: kernel row r = 2u + 1 - th, column s
@@ -3139,8 +3149,9 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
     for (int pre = 0; pre < 2; ++pre) {
       if (t + pre * G < ntiles) {
         tile_pos(t + pre * G, img, ty0, tx0);
+        const TileSrc ts = tile_src(img, ty0, tx0);
 #pragma unroll
-        for (int r = 0; r < PR; ++r) issue_piece(r, img, ty0, tx0, pre);
+        for (int r = 0; r < PR; ++r) issue_piece(r, ts, pre);
       }
     }
   }
@@ -3172,10 +3183,10 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
         const bf16x8 bf = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
         acc[lt] = Mma<bf16_t>::run(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, bf), acc[lt]);
       }
-      if (more) {
+      if (more && j == 0) {
+        const TileSrc ts = tile_src(nimg, nty0, ntx0);
 #pragma unroll
-        for (int r = 0; r < PR; ++r)
-          if (j == 0) issue_piece(r, nimg, nty0, ntx0, nstage);
+        for (int r = 0; r < PR; ++r) issue_piece(r, ts, nstage);
       }
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
