@@ -164,6 +164,12 @@ __device__ __forceinline__ vg_srd_t vg_make_srd(const void* base) {       // raw
 __device__ __forceinline__ void lds_dma16_buf(vg_srd_t srd, unsigned voff, unsigned lds_byte_off) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_byte_off), "v"(voff), "s"(srd) : "memory");
 }
+// ... and with M0 put back, for kernels that also use lds_dma16 / lds_dma16_s
+__device__ __forceinline__ void lds_dma16_bufk(vg_srd_t srd, unsigned voff, unsigned lds_byte_off) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_byte_off), "v"(voff), "s"(srd) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
@@ -848,11 +854,8 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   const int cch = p.C / KC;                                 // real chunks per pixel
   const int cchunks = S2 ? 4 * cch : cch;                   // S2: plane-major virtual chunks
   const size_t ktot = (size_t)(S2 ? 16 : NTAPS) * p.C;      // S2: rows of the ordinary packed 4x4 forward weights
-  const unsigned char* zsrc = (const unsigned char*)vg_zero_block;
   const unsigned char* __restrict__ wg = (const unsigned char*)((const T*)p.w + ((size_t)phase * p.Npad + n0) * ktot);
   const int cbytes = p.C * EB;          // one tap of one weight row
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* gptr_t;
 
   unsigned boff[LPB];       // weight piece of this thread: byte offset inside the [BN][ktot] slab
 #pragma unroll
@@ -899,6 +902,7 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   // go out as wave-uniform base + 32-bit lane offset (lds_dma16_s): the compiler does not see these DMAs, every wait
   // for them is one of the kernel's own counted vmcnt waits.
   const unsigned smem0 = lds_addr_of(smem);
+  const vg_srd_t xsrd = vg_make_srd(xg);
   auto dma_b = [&](int i, int itap, int icc, int slot) {
     const unsigned char* src;
     if constexpr (S2) {
@@ -915,10 +919,12 @@ __device__ __forceinline__ void igemm3_body(const IgemmParams& p) {
   auto dma_h = [&](int rd, int icc, int hboff) {
     if constexpr (S2) {
       if (pval[rd]) {
+        // a piece outside the image in this plane gets offset 0xFFFFFFFF: the buffer resource writes zeros for it
+        // (lds_dma16_buf).  Piece offsets are 32-bit two's complement from the tensor's start (launcher: < 2^31 bytes).
         const int plane = icc >> p.lgc, ic = icc & (cch - 1);
-        const long add = (long)((plane >> 1) * p.W + (plane & 1)) * p.Cs * EB + (long)ic * 64;
-        const unsigned char* src = ((pval[rd] >> plane) & 1) ? xg + ((long)(int)poff[rd] + add) : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lds_ptr_t)(smem + hboff + (rd * NT + wave * 64) * 16), 16, 0, 0);
+        const unsigned add = (unsigned)(((plane >> 1) * p.W + (plane & 1)) * p.Cs * EB + ic * 64);
+        const unsigned voff = ((pval[rd] >> plane) & 1) ? poff[rd] + add : 0xFFFFFFFFu;
+        lds_dma16_bufk(xsrd, voff, smem0 + hboff + (rd * NT + wave * 64) * 16);
       }
     } else {
       if (poff[rd] != 0xFFFFFFFFu) lds_dma16_s(xg + (size_t)icc * 64, poff[rd], smem0 + hboff + (rd * NT + wave * 64) * 16);
