@@ -1626,7 +1626,9 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
   };
   // ACC: the old values of the previous tile's rows are requested in one burst when the K loop starts and the stores
   // sit in its second half; the end-of-tile wait then lets the stores issued after the last halo round stay in flight
-  constexpr int ST0 = ACC ? 18 : 0;
+  // (all variants since round 3: with the stores in the first half of the K loop the end-of-tile wait for the halo also
+  // waited for every store of the previous tile, ~15 % of a block's time in the s_memtime stamps)
+  constexpr int ST0 = CCH * NTAPS * 2 - 18 < 18 ? CCH * NTAPS * 2 - 18 : 18;      // K steps: CCH * NTAPS * 2
 
 #ifdef VG_ABLATE   // s_memtime ticks per stage, summed over the block's tiles (wave 0): tests/gpu_igemm4_stamps.py
   unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -1776,7 +1778,7 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
     {
       // stores issued after the last halo round (K step 2*HRN-1): they may stay in flight
       constexpr int LATE = [] { int n = 0; for (int s_ = 0; s_ < 8; ++s_) n += ST0 + 2 + 2 * s_ >= 2 * HRN; return n; }();      // (a lower bound without the split)      // the last DMA goes out in step 2 * HRN - 1
-      if (ACC && has_prev && VG_ABLATE_LEVEL < 2) wait_vmcnt<LATE>(); else wait_vmcnt<0>();
+      if (has_prev && VG_ABLATE_LEVEL < 2) wait_vmcnt<LATE>(); else wait_vmcnt<0>();
     }
     VG_T(3);
     tile = next;
@@ -1956,7 +1958,7 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     *(u32x4*)store_ptr(sidx) = v;
   };
   constexpr int NST = 2 * TH;                  // stores per wave per tile
-  constexpr int ST0 = ACC ? 2 * HRN + 2 : 0;   // ACC: old values requested at K step 0, stores behind the halo rounds
+  constexpr int ST0 = 2 * HRN + 2;             // stores behind the halo rounds (ACC: old values requested at K step 0): they stay in flight over the tile's end
   static_assert(2 * HRN <= KSTEPS - 8 && ST0 + 2 * NST + 2 <= KSTEPS, "halo rounds and stores fit the K loop");
 
   int tile = tile_of(0);
@@ -2088,7 +2090,7 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
     __builtin_amdgcn_wave_barrier();
     pdst = yg + ((((size_t)img * p.OH + ty0) * p.OW + tx0 + (lane >> 2)) * BN + 32 * wave + (lane & 3) * PIECE);
     has_prev = true;
-    if (ACC && k > 0) wait_vmcnt<NST>(); else wait_vmcnt<0>();     // ACC: this tile's stores all sit behind the last halo round
+    if (k > 0) wait_vmcnt<NST>(); else wait_vmcnt<0>();            // this tile's stores all sit behind the last halo round
     tile = next;
   }
   if (has_prev) {
