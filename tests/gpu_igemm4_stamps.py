@@ -1,7 +1,7 @@
 """Where a block's time goes inside igemm4: s_memtime ticks per stage summed over its tiles (ablation build only)."""
 import ctypes as C, os, torch
 from vae_gan_amd import lib as L
-L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libvg_hip_ablate.so")
+L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), f"libvg_hip_{os.environ.get('VG_LIB_EXP', 'ablate')}.so")      # VG_LIB_EXP=<tag>: another -DVG_ABLATE=1 build
 from gpu_ops_check import make_desc, pack
 
 def run(n=64, h=256, w=256):

@@ -1,9 +1,12 @@
 """Weight-gradient microbench at the VQ-VAE-GAN layer shapes (batch 64, bf16): per-tap kernel vs spatial-tile kernel."""
-import ctypes as C, torch
+import ctypes as C, os, torch
 from vae_gan_amd import lib as L
+if os.environ.get("VG_LIB_EXP"):      # A/B against another build: libvg_hip_<tag>.so
+    _v = os.environ["VG_LIB_EXP"]
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), f"libvg_hip_{'exp' if _v == '1' else _v}.so")
 from gpu_ops_check import make_desc
 
-def run(n, h, w, ci, co, k, stride, pad, iters=5):
+def run(n, h, w, ci, co, k, stride, pad, iters=20):
     lib = L.load(); dtype = torch.bfloat16
     d = make_desc(n, h, w, ci, co, k, stride, pad, dtype)
     x = torch.randn(n, h, w, d.xcs, device="cuda").to(dtype)
@@ -13,7 +16,7 @@ def run(n, h, w, ci, co, k, stride, pad, iters=5):
     flops = 2.0 * n * d.oh * d.ow * co * ci * k * k
     gb = (x.numel() + gy.numel()) * 2 / 1e9
     res = []
-    for mode in (1, 3, 4):
+    for mode in ((4,) if os.environ.get('VG_WGP_FAST') else (1, 3, 4)):
         lib.vg_set_wgrad_kernel(mode)
         fn = lambda: lib.vg_conv_wgrad(C.byref(d), x.data_ptr(), gy.data_ptr(), dw.data_ptr(), ws.data_ptr(), 0, L.stream())
         fn(); torch.cuda.synchronize()
