@@ -20,8 +20,15 @@ for m in re.finditer(r"^(_Z\w+):", txt, re.M):
     if not re.search(r"buffer_load_dwordx4 .* lds", body):
         continue
     uses = [l.strip() for l in body.split("\n") if re.search(r"\bm0\b", l)]
-    other = [u for u in uses if not re.fullmatch(r"s_mov_b32 m0, s\d+", u)]
-    print(f"{name[:70]:70s} M0 writes by the helper: {len(uses) - len(other)}, other M0 accesses: {len(other)}")
+    writes = [u for u in uses if re.fullmatch(r"s_mov_b32 m0, s\d+", u)]
+    saves = [u for u in uses if re.fullmatch(r"s_mov_b32 s\d+, m0", u)]
+    other = [u for u in uses if u not in writes and u not in saves]
+    if saves:      # kernels on the saving helpers (lds_dma16_s / lds_dma16_bufk: save, write, restore around every DMA)
+        if len(writes) != 2 * len(saves):
+            other += [f"{len(saves)} saves of M0 against {len(writes)} writes: not save / write / restore triples"]
+        print(f"{name[:70]:70s} M0 saved and restored around {len(saves)} DMAs, other M0 accesses: {len(other)}")
+    else:
+        print(f"{name[:70]:70s} M0 writes by the helper: {len(writes)}, other M0 accesses: {len(other)}")
     for u in other:
         print("    ", u)
     bad += len(other)
