@@ -2816,9 +2816,13 @@ __device__ inline Wg3Walk wg3_walk(int b, int pairs, int G, int ntiles, int xcd)
   return w;
 }
 
+#ifndef VG_WG3_TH222
+#define VG_WG3_TH222 8
+#endif
+static constexpr int wg3_th(int nob, int ncb, int ks) { return (nob == 2 && ncb == 2 && ks == 2) ? VG_WG3_TH222 : 4; }
 template <int NOB, int NCB, int KS>
 struct Wg3Cfg {
-  static constexpr int TH = 4, TW = 32, R = 3, S = 3, NTAPS = 9;
+  static constexpr int TH = wg3_th(NOB, NCB, KS), TW = 32, R = 3, S = 3, NTAPS = 9;
   static constexpr int HH = TH + R - 1, HS = TW + S - 1;              // 6 x 34 halo pixels
   static constexpr int DYP = TH * TW / 16;                            // 16-pixel (1 KiB) DMA pieces per dy chunk image
   static constexpr int XP = (HH * HS + 15) / 16;                      // ... per x halo chunk image
@@ -3250,11 +3254,12 @@ static Wg3Plan wg3_plan(const WgradParams& p, int R, int S, int dtype) {
     else if (p.Opad > 32) { q.nob = 2; q.ncb = 1; q.ks = 2; }
     else { q.nob = 1; q.ncb = 1; q.ks = 4; }
   } else if (p.in_s == 1 && R == 3 && S == 3 && p.OW >= 24) {
-    q.kind = 1; th = 4; tw = 32;
+    q.kind = 1; tw = 32;
     if (p.Opad <= 32) { q.nob = 1; q.ncb = 2; q.ks = 4; }
     else if (p.Cpad <= 32) { q.nob = 2; q.ncb = 1; q.ks = 4; }
     else if (g_wgrad_kernel >= 4 && p.Opad >= 128) { q.nob = 4; q.ncb = 2; q.ks = 1; }      // 128 x 64 slab, no row split
     else { q.nob = 2; q.ncb = 2; q.ks = 2; }
+    th = wg3_th(q.nob, q.ncb, q.ks);
   } else {
     return q;
   }
