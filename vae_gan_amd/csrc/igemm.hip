@@ -3051,16 +3051,20 @@ static int launch_wgrad3(const WgradParams& p0, hipStream_t st) {
 // pixel rows (conflict-free transposed reads at immediate offsets).  A wave keeps one 32 x 32 block for the 8
 // taps of one row parity (128 accumulators); waves = NOB x NCB x 2 tap halves x KS row splits.
 // =============================================================================================
+#ifndef VG_WG3S2_TH411
+#define VG_WG3S2_TH411 8
+#endif
+static constexpr int wg3s2_th(int nob, int ncb, int ks) { return (nob == 4 && ncb == 1 && ks == 1) ? VG_WG3S2_TH411 : 4; }
 template <int NOB, int NCB, int KS>
 struct Wg3s2Cfg {
-  static constexpr int TH = 4, TW = 16, PH = TH + 1, PW = TW + 1, PLANE = PH * PW;      // 85 pixels per parity plane
+  static constexpr int TH = wg3s2_th(NOB, NCB, KS), TW = 16, PH = TH + 1, PW = TW + 1, PLANE = PH * PW;      // 85 pixels per parity plane (TH = 4)
   static constexpr int DYP = TH * TW / 16;                           // 4 pieces per dy chunk image
   static constexpr int XP = (4 * PLANE + 15) / 16;                   // 22 pieces per x chunk image (4 planes)
   static constexpr int DYB = DYP * 1024, XB = XP * 1024;
   static constexpr int STAGE = NOB * DYB + NCB * XB;
   static constexpr int NPIECE = NOB * DYP + NCB * XP;
   static constexpr int PR = (NPIECE + 7) / 8;
-  static constexpr int NST = 3;
+  static constexpr int NST = 3 * STAGE <= 160 * 1024 ? 3 : 2;
   static constexpr int LDS = NST * STAGE;
   static constexpr int BO = 32 * NOB, BC = 32 * NCB;
 };
@@ -3158,7 +3162,7 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   {
     int img, ty0, tx0;
 #pragma unroll
-    for (int pre = 0; pre < 2; ++pre) {
+    for (int pre = 0; pre < NST - 1; ++pre) {
       if (t + pre * G < ntiles) {
         tile_pos(t + pre * G, img, ty0, tx0);
         const TileSrc ts = tile_src(img, ty0, tx0);
@@ -3169,14 +3173,14 @@ __global__ __launch_bounds__(512) void wgrad3s2_kernel(const WgradParams p) {
   }
   int stage = 0;
   for (; t < ntiles; t += G) {
-    if (t + G < ntiles) wait_vmcnt<PR>();
+    if (NST == 3 && t + G < ntiles) wait_vmcnt<PR>();                 // the next tile's pieces may stay in flight
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const bool more = t + 2 * G < ntiles;
+    const bool more = t + (NST - 1) * G < ntiles;
     int nimg = 0, nty0 = 0, ntx0 = 0;
-    if (more) tile_pos(t + 2 * G, nimg, nty0, ntx0);
-    const int nstage = stage + 2 >= NST ? stage + 2 - NST : stage + 2;
+    if (more) tile_pos(t + (NST - 1) * G, nimg, nty0, ntx0);
+    const int nstage = stage + NST - 1 >= NST ? stage - 1 : stage + NST - 1;
     const unsigned char* sA = smem + stage * STAGE + abase;
     const unsigned char* sB = smem + stage * STAGE + bbase;
 #pragma unroll
@@ -3249,10 +3253,11 @@ static Wg3Plan wg3_plan(const WgradParams& p, int R, int S, int dtype) {
     return q;                                                // piece offsets are 32-bit inside one image
   int th, tw;
   if (p.in_s == 2 && R == 4 && S == 4 && p.dy_[0] == -1 && p.dx_[0] == -1 && p.OW >= 8) {
-    q.kind = 2; th = 4; tw = 16;
+    q.kind = 2; tw = 16;
     if (p.Opad >= 128) { q.nob = 4; q.ncb = 1; q.ks = 1; }
     else if (p.Opad > 32) { q.nob = 2; q.ncb = 1; q.ks = 2; }
     else { q.nob = 1; q.ncb = 1; q.ks = 4; }
+    th = wg3s2_th(q.nob, q.ncb, q.ks);
   } else if (p.in_s == 1 && R == 3 && S == 3 && p.OW >= 24) {
     q.kind = 1; tw = 32;
     if (p.Opad <= 32) { q.nob = 1; q.ncb = 2; q.ks = 4; }
