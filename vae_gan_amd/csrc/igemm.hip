@@ -2917,15 +2917,20 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
     lds_dma16_buf(srd, ok ? poff[r] : 0xFFFFFFFFu, smem_base + (unsigned)(stage * STAGE + pdst[r]));
   };
 
-  f32x16 acc[NTAPS];
+  // v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it than on 32x32x16): a tile row of 32 pixels is the K of
+  // one MFMA, the 32 x 32 block of a tap is four 16 x 16 blocks (o half oh, c half ch).  acc[tap][oh*2 + ch][r]:
+  // o = oh*16 + 4*kb + r, c = ch*16 + m16.
+  f32x4 acc[NTAPS][4];
 #pragma unroll
   for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int q = 0; q < 4; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // transposed-read lane term: lane (tq = li>>2, tp = li&3) of a 16-lane group addresses pixel row tq, channels 4tp..4tp+3
-  const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
-  const int lterm = (8 * h + tq) * 64 + (16 * g16 + 4 * tp) * 2;
+  // transposed-read lane term: lane (tq = li>>2, tp = li&3) of a 16-lane group addresses pixel row tq, channels 4tp..4tp+3;
+  // the group kb = lane / 16 holds pixels 8*kb .. 8*kb + 7 of the row (the 16-channel half is + 32 bytes)
+  const int m16 = lane & 15, kb = lane >> 4;
+  const int li = lane & 15, tq = li >> 2, tp = li & 3;
+  const int lterm = (8 * kb + tq) * 64 + (4 * tp) * 2;
   const int abase = ob * DYB + ks * TW * 64 + lterm;                 // dy image of this wave's o block, first own row
   const int bbase = NOB * DYB + cb * XB + ks * HS * 64 + lterm;      // x halo image of this wave's c block
 
@@ -2964,25 +2969,32 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
       for (int r = 0; r < PR; ++r) issue_piece(r, ts, nstage);
     }
 #pragma unroll
-    for (int kstep = 0; kstep < KSTEPS; ++kstep) {
-      const int j = kstep >> 1, kx = kstep & 1;
+    for (int j = 0; j < ROWS; ++j) {
       const int y = j * KS;                                           // + ks (in the base)
-      bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW + kx * 16) * 64));
-      bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW + kx * 16 + 4) * 64));
-      const bf16x8 a = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+      u32x4 a[2];
+#pragma unroll
+      for (int oh = 0; oh < 2; ++oh) {
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW) * 64 + oh * 32));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sA + (y * TW + 4) * 64 + oh * 32));
+        a[oh] = __builtin_bit_cast(u32x4, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+      }
 #pragma unroll
       for (int tap = 0; tap < NTAPS; ++tap) {
-        const int hp = VG_DBG(16) ? (y * HS + kx * 16) : (y + tap / 3) * HS + kx * 16 + tap % 3;
-        bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + hp * 64));
-        bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64));
-        const bf16x8 b = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-        acc[tap] = Mma<bf16_t>::run(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, b), acc[tap]);
+        const int hp = VG_DBG(16) ? (y * HS) : (y + tap / 3) * HS + tap % 3;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + hp * 64 + ch * 32));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(sB + (hp + 4) * 64 + ch * 32));
+          const u32x4 b = __builtin_bit_cast(u32x4, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+          for (int oh = 0; oh < 2; ++oh) acc[tap][oh * 2 + ch] = mma16x16x32(a[oh], b, acc[tap][oh * 2 + ch]);
+        }
       }
     }
     stage = stage + 1 == NST ? 0 : stage + 1;
   }
 
-  // acc[tap][r]: row (o) = (r&3) + 8*(r>>2) + 4*h, column (c) = l32
+  // acc[tap][oh*2 + ch][r]: row (o) = oh*16 + 4*kb + r, column (c) = ch*16 + m16
   // Every (tile group, row split) pair owns one partial image of dW and writes it with plain stores; the unpack kernel
   // sums the partials in a fixed order.  (One pass of f32 atomics into a single image cost 50-100 us per launch, a
   // fifth of the kernel, and made the gradient depend on the order the blocks finished in.)
@@ -2999,14 +3011,14 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
 #pragma unroll
         for (int tap = T0[half]; tap < T1[half]; ++tap)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) xch[((tap - T0[half]) * 16 + r) * 64] = acc[tap][r];
+          for (int r = 0; r < 16; ++r) xch[((tap - T0[half]) * 16 + r) * 64] = acc[tap][r >> 2][r & 3];
       }
       __syncthreads();
       if (ks == 0) {
 #pragma unroll
         for (int tap = T0[half]; tap < T1[half]; ++tap)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[tap][r] += xch[((tap - T0[half]) * 16 + r) * 64];
+          for (int r = 0; r < 16; ++r) acc[tap][r >> 2][r & 3] += xch[((tap - T0[half]) * 16 + r) * 64];
       }
       __syncthreads();
     }
@@ -3014,17 +3026,20 @@ __global__ __launch_bounds__(512) void wgrad3_kernel(const WgradParams p) {
   }
   const size_t rowstride = (size_t)NTAPS * p.Cpad;
   float* __restrict__ part = p.dw + (size_t)(KS == 2 ? g : g * KS + ks) * p.part_elems;
-  const int c = c0 + cb * 32 + l32;
-  if (c < p.Cpad && !VG_DBG(128)) {
+  if (!VG_DBG(128)) {
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = o0 + ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (o < p.Opad) part[(size_t)o * rowstride + (size_t)tap * p.Cpad + c] = acc[tap][r];
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + cb * 32 + (q & 1) * 16 + m16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + ob * 32 + (q >> 1) * 16 + 4 * kb + r;
+          if (c < p.Cpad && o < p.Opad) part[(size_t)o * rowstride + (size_t)tap * p.Cpad + c] = acc[tap][q][r];
+        }
       }
   }
-  if (VG_DBG(128) && acc[0][0] == 123.f) p.dw[0] = acc[1][1] + acc[8][15];    // keep the accumulators alive
+  if (VG_DBG(128) && acc[0][0][0] == 123.f) p.dw[0] = acc[1][0][1] + acc[8][3][3];    // keep the accumulators alive
 }
 
 template <int NOB, int NCB, int KS>
