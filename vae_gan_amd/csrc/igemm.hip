@@ -106,6 +106,16 @@ __device__ __forceinline__ f32x4 mma16x16x32(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Sum and sum of squares of a pair of bf16 values into f32 accumulators with one v_dot2c_f32_bf16 each (the values ARE the
+// bf16-rounded pre-activation the statistics are defined on: no conversion back to f32, no separate multiply):
+// statistics-only epilogues of the weights-stationary kernels, where one wave per SIMD pays for every VALU instruction.
+typedef __bf16 vg_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_sum(vg_bf16x2 q, float s) {
+  const vg_bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+  return __builtin_amdgcn_fdot2_f32_bf16(q, one, s, false);
+}
+__device__ __forceinline__ float dot2_sq(vg_bf16x2 q, float s) { return __builtin_amdgcn_fdot2_f32_bf16(q, q, s, false); }
+
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   // bijective: blocks that share an XCD (bid % 8) get one contiguous range of logical ids
   int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
@@ -1752,8 +1762,9 @@ __global__ __launch_bounds__(256) void igemm4_kernel(const IgemmParams p) {
             const int row = mh * 16 + r;
             f32x2 v = f32x2{acc[i][mh][nt][r], acc[i][mh][nt][r + 1]} + bv[nt];
             bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
-            if (ST || LR) v = __builtin_convertvector(q, f32x2);
-            if (ST) { a1 += v; a2 += v * v; }
+            if (ST && !LR) { a1[0] = dot2_sum(q, a1[0]); a2[0] = dot2_sq(q, a2[0]); }      // (a1[1], a2[1] stay zero)
+            if (LR) v = __builtin_convertvector(q, f32x2);
+            if (ST && LR) { a1 += v; a2 += v * v; }
             if (LR) {
               const f32x2 w = v * VG_LRELU_SLOPE;
               f32x2 m;
@@ -2068,8 +2079,9 @@ __global__ __launch_bounds__(256) void igemm4c_kernel(const IgemmParams p) {
               const int row = mh * 16 + r;
               f32x2 v = f32x2{acc[i][mh][nt][r], acc[i][mh][nt][r + 1]} + bv[nt];
               bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
-              if (ST || LR) v = __builtin_convertvector(q, f32x2);
-              if (ST) { a1[nt] += v; a2[nt] += v * v; }
+              if (ST && !LR) { a1[nt][0] = dot2_sum(q, a1[nt][0]); a2[nt][0] = dot2_sq(q, a2[nt][0]); }
+              if (LR) v = __builtin_convertvector(q, f32x2);
+              if (ST && LR) { a1[nt] += v; a2[nt] += v * v; }
               if (LR) {
                 const f32x2 w = v * VG_LRELU_SLOPE;
                 f32x2 m;
