@@ -2785,12 +2785,13 @@ static int launch_wgrad(const WgradParams& p0, hipStream_t st) {
 //
 // The kernel above gives every tap its own blocks, so x and dy travel L2 -> LDS once per tap (18 tensor
 // passes for a 3x3) and it is bound by that traffic.  Here a block of 8 waves owns one (BO x BC) slab of
-// dW for ALL nine taps and walks over 4 x 32 pixel tiles of the output: per tile the dy tile and the x halo
-// (6 x 34 pixels) are brought in ONCE by LDS-DMA, three tiles deep, and the taps read their shifted
-// [pixel][channel] operands with transposed LDS reads (plain 64-byte pixel rows are conflict free for
-// ds_read_b64_tr_b16, so a tap shift is an immediate offset).  A wave keeps one 32 x 32 block of every tap
-// in registers (144 accumulators) over its share of the tile rows; the slab is added to the f32
-// workspace with atomics once, at the end.  One barrier per tile, counted vmcnt.
+// dW for ALL nine taps and walks over TH x 32 pixel tiles of the output (TH = 4; 8 for the 64 x 64 slab, whose stages
+// then still fit twice): per tile the dy tile and the x halo ((TH + 2) x 34 pixels) are brought in ONCE by LDS-DMA,
+// two or three tiles deep (what 160 KB hold), and the taps read their shifted [pixel][channel] operands with transposed
+// LDS reads (ds_read_b64_tr_b16 on plain 64-byte pixel rows: a tap shift is an immediate offset).  A wave keeps one
+// 32 x 32 block of every tap in registers (144 accumulators, four 16 x 16 MFMA blocks per tap: v_mfma_f32_16x16x32_bf16,
+// a 32-pixel tile row is its K) over its share of the tile rows; every tile group writes its slab to a partial image
+// of its own, summed in a fixed order by wgrad_unpack_kernel.  One barrier per tile, counted vmcnt.
 // =============================================================================================
 // tile groups per slab pair: one block per CU (LDS-limited), at least; never more groups than tiles
 static int wg3_groups(int pairs, int n, int oh, int ow, int th, int tw) {
