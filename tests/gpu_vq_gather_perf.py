@@ -2,6 +2,8 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from vae_gan_amd import lib as L
+if os.environ.get('VG_LIB_EXP'):
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), f"libvg_hip_{os.environ['VG_LIB_EXP']}.so")
 lib = L.load()
 N, K, D = 65536, 512, 64
 z = torch.randn(N, D, device="cuda"); cb = torch.randn(K, D, device="cuda") * 0.5

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const float* __restrict_
 // The same with the EMA statistics privatised in LDS (k*d + k floats <= 144 KB): the rows of a batch pile onto few
 // codes (a fresh codebook: nearly all onto a handful), so global f32 atomics on esum[code][:] serialise (230 us for
 // 65,536 x 64 at K = 512).  A block of 1024 threads accumulates its rows with LDS atomics and flushes the non-zero
-// entries once.
+// entries once (round 3: a wave per row, 256 blocks: 100 -> 47 us).
 __global__ __launch_bounds__(1024) void vq_gather_lds_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                              const int64_t* __restrict__ idx, int64_t rows, int K, int D,
                                                              float* __restrict__ zq, double* __restrict__ sse,
@@ -611,28 +611,49 @@ __global__ __launch_bounds__(1024) void vq_gather_lds_kernel(const float* __rest
   const int total = K * D + K;
   for (int i = threadIdx.x; i < total; i += 1024) s_acc[i] = 0.f;
   __syncthreads();
-  const int tpr = D / 4;
-  const int rpb = 1024 / tpr;
-  const int c4 = threadIdx.x % tpr, rr = threadIdx.x / tpr;
+  // A WAVE per row, a lane per channel (c = lane, lane + 64, ...): the 64 lanes of an LDS atomic then hit 64 different
+  // banks.  (A row per 16 lanes with four channels each put the four rows of a wave on the same 16 banks, every code row
+  // starting at bank 0: f32 LDS atomics four lanes deep per bank were what the kernel spent its time on.)  U rows in
+  // flight per wave: a row is two dependent memory latencies (index, then code vector).
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int U = 4;
   float local = 0.f;
-  if (rr < rpb) {
-    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
-      int code = (int)idx[r];
-      if (code < 0) code = 0;
-      if (code >= K) code = K - 1;
-      const f32x4 zv = *(const f32x4*)(z + (size_t)r * D + c4 * 4);
-      const f32x4 qv = *(const f32x4*)(cb + (size_t)code * D + c4 * 4);
-      f32x4 o;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t r0 = (int64_t)blockIdx.x * 16 + wave; r0 < rows; r0 += U * stride) {
+    int code[U];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float diff = qv[e] - zv[e];
-        o[e] = zv[e] + diff;
-        local += diff * diff;
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * stride;
+      int c = r < rows ? (int)idx[r] : 0;
+      if (c < 0) c = 0;
+      if (c >= K) c = K - 1;
+      code[u] = c;
+    }
+    for (int c0 = 0; c0 < D; c0 += 64) {
+      const int c = c0 + lane;
+      float zv[U], qv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * stride;
+        const bool ok = r < rows && c < D;
+        zv[u] = ok ? z[(size_t)r * D + c] : 0.f;
+        qv[u] = ok ? cb[(size_t)code[u] * D + c] : 0.f;
       }
-      *(f32x4*)(zq + (size_t)r * D + c4 * 4) = o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(&s_acc[(size_t)code * D + c4 * 4 + e], zv[e]);
-      if (c4 == 0) atomicAdd(&s_cnt[code], 1.0f);
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * stride;
+        if (r < rows && c < D) {
+          const float diff = qv[u] - zv[u];
+          local += diff * diff;
+          zq[(size_t)r * D + c] = zv[u] + diff;
+          atomicAdd(&s_acc[(size_t)code[u] * D + c], zv[u]);
+        }
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (r0 + u * stride < rows) atomicAdd(&s_cnt[code[u]], 1.0f);
     }
   }
   __syncthreads();
@@ -694,9 +715,10 @@ extern "C" int vg_vq_gather(const float* z, const float* codebook, const int64_t
   const int det = vg_det_mode();
   if (esum != nullptr && lds <= 144 * 1024 && rows >= 8192 && !det) {
     VG_HIP(vg_lds_attr((const void*)vq_gather_lds_kernel, 144 * 1024));
-    const int rpb1 = 1024 / (d / 4);
-    int64_t nb = vg_ceil_div(rows, (int64_t)rpb1 * 16);        // >= 16 rows per thread before a block pays its flush
-    if (nb > 128) nb = 128;
+    // one block per CU (its LDS holds nothing else), >= 16 rows per wave before a block pays for zeroing and flushing its
+    // 131 KB: 65,536 x 64 at K = 512: 64 us with 128 blocks, 47 with 256, 53 with 512
+    int64_t nb = vg_ceil_div(rows, (int64_t)16 * 16);
+    if (nb > 256) nb = 256;
     hipLaunchKernelGGL(vq_gather_lds_kernel, dim3((unsigned)nb), dim3(1024), lds, (hipStream_t)stream, z, codebook, idx, rows,
                        k, d, zq, sse, counts, esum);
     VG_LAUNCH_CHECK();
