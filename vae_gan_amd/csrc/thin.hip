@@ -449,28 +449,38 @@ __global__ __launch_bounds__(256, 3) void thin_out3_kernel(const ThinParams p) {
 
 // ---------------------------------------------------------------------------------------------
 // weight gradient.  acc[n][(r,s,c)] = sum_q wide[q][n] * thin[q*ST - pad + (r,s)][c] over all pixels q of the wide
-// tensor: K = pixels.  Persistent blocks walk 8 x 32 pixel tiles; both operands are written TRANSPOSED into LDS
-// ([channel][pixel], conflict-free 2-byte writes: a lane owns one pixel) so that a fragment is 8 consecutive pixels.
+// tensor: K = pixels.  Persistent blocks walk 8 x 32 pixel tiles.  Both operands stay [pixel][channel] in LDS, as they
+// are in memory, and are read with transposed LDS reads (ds_read_b64_tr_b16, as in wgrad3): the wide tile as two
+// 32-channel images of plain 64-byte pixel rows, the thin operand straight from the 8-byte pixels of the halo, every
+// lane addressing the pixel its tap (r, s) shifts to.  (Round 2 wrote both operands transposed into LDS with 2-byte
+// stores, 100 per thread and tile, and was bound by them: 173 us for 570 MB.)
 // Every block writes one 64 x 64 partial image; thin_wgrad_finish sums them in a fixed order into OIHW.
 // ---------------------------------------------------------------------------------------------
 template <int R, int ST>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p) {
-  constexpr int TH = 8, TW = 32, HH = (TH - 1) * ST + R, HW = (TW - 1) * ST + R, HWP = HW + (HW & 1) + 2, RS = 264;
+  constexpr int TH = 8, TW = 32, HH = (TH - 1) * ST + R, HW = (TW - 1) * ST + R, HWP = HW + (HW & 1) + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
-  bf16_t* wT = (bf16_t*)tsm;                     // [64][RS]
-  bf16_t* cT = wT + 64 * RS;                     // [64][RS]
-  u32x2* halo = (u32x2*)(cT + 64 * RS);          // [HH][HWP]
+  unsigned char* wI = tsm;                       // [2 chunks of 32 channels][256 pixels][64 B]
+  u32x2* halo = (u32x2*)(tsm + 2 * 256 * 64);    // [HH][HWP] 4-channel pixels
+  typedef __attribute__((address_space(3))) bf16x4* tr_ptr_t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
   const int tpi = p.tilesX * p.tilesY;
   const u32x2* __restrict__ tg = (const u32x2*)p.thin;
-  for (int idx = tid; idx < 64 * RS; idx += 256) cT[idx] = (bf16_t)0.f;      // rows of taps outside R x R stay zero
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int mblk = wave >> 1, nblk = wave & 1;
   const int py = tid >> 5, px = tid & 31;
+  // transposed-read lane terms: lane (tq, tp) of the 16-lane group (h, g16) addresses pixel 8h + tq of the K step.
+  // A: channels 16*g16 + 4*tp .. + 3 of its 32-channel image.  B: the 8-byte pixel that tap (r, s) = (2*nblk + g16, tp)
+  // shifts to (columns 16*g16 + 4*tp .. + 3 of the block = that tap's four channels); taps beyond R x R address the
+  // last real one (their accumulator columns are never read by the finish kernel).
+  const int li = lane & 15, g16 = (lane >> 4) & 1, tq = li >> 2, tp = li & 3;
+  const int a_l = mblk * (256 * 64) + (8 * h + tq) * 64 + (16 * g16 + 4 * tp) * 2;
+  const int tr_ = min(2 * nblk + g16, R - 1), ts_ = min(tp, R - 1);
+  const int b_l = (tr_ * HWP + (8 * h + tq) * ST + ts_) * 8;
   // the NEXT tile's pixels are requested into registers before the current tile is computed (HBM latency under the
-  // transposes and MFMAs; single-buffered with 2 blocks per CU the loop was latency-bound)
+  // LDS writes and MFMAs)
   constexpr int NH = (HH * HWP + 255) / 256;
   u32x4 nw_[8];
   u32x2 nh_[NH];
@@ -504,27 +514,21 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p) {
     for (int u = 0; u < NH; ++u)
       if (tid + 256 * u < HH * HWP) halo[tid + 256 * u] = nh_[u];
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) {
-      const bf16x8 e = __builtin_bit_cast(bf16x8, nw_[pc]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) wT[(pc * 8 + k) * RS + tid] = e[k];
-    }
+    for (int pc = 0; pc < 8; ++pc) *(u32x4*)(wI + (pc >> 2) * (256 * 64) + tid * 64 + (pc & 3) * 16) = nw_[pc];
     if (tile + (int)gridDim.x < p.ntiles) request(tile + gridDim.x);
     __syncthreads();
+    const unsigned char* hb = (const unsigned char*)halo;
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int s = 0; s < R; ++s) {
-        const bf16x4 e = __builtin_bit_cast(bf16x4, halo[(py * ST + r) * HWP + px * ST + s]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) cT[((r * 4 + s) * 4 + c) * RS + tid] = e[c];
-      }
-    __syncthreads();
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-      const u32x4 fa = *(const u32x4*)(wT + (mblk * 32 + l32) * RS + ks * 16 + 8 * h);
-      const u32x4 fb = *(const u32x4*)(cT + (nblk * 32 + l32) * RS + ks * 16 + 8 * h);
-      acc = mfma16(fa, fb, acc);
+    for (int ks = 0; ks < 16; ++ks) {                  // 16 pixels of tile row ks / 2 per step
+      const int ao = a_l + ks * 16 * 64;
+      const int bo = b_l + ((ks >> 1) * ST * HWP + (ks & 1) * 16 * ST) * 8;
+      const bf16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(wI + ao));
+      const bf16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(wI + ao + 4 * 64));
+      const bf16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(hb + bo));
+      const bf16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((tr_ptr_t)(hb + bo + 4 * ST * 8));
+      const bf16x8 fa = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+      const bf16x8 fb = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+      acc = mfma16(__builtin_bit_cast(u32x4, fa), __builtin_bit_cast(u32x4, fb), acc);
     }
   }
   float* __restrict__ part = p.part + (size_t)blockIdx.x * 4096;
@@ -585,8 +589,8 @@ static void thin_fill(const vg_conv_desc* d, int kind, ThinParams& p) {
   else { p.TH_ = d->oh; p.TW_ = d->ow; p.WH = d->h; p.WW = d->w; p.nw = d->ci; p.nt = d->co; }
 }
 template <int R> static constexpr int thin_out_lds() { return (7 * 32 * 72 + 64 * 72) * 2 + 6 * 34 * (R * R * 4 + 4) * 4; }
-template <int R, int ST> static constexpr int thin_wgrad_lds() {
-  return 2 * 64 * 264 * 2 + ((8 - 1) * ST + R) * ((32 - 1) * ST + R + (((32 - 1) * ST + R) & 1) + 2) * 8;
+template <int R, int ST> static constexpr int thin_wgrad_lds() {      // the wide tile as two 32-channel images + the thin halo
+  return 2 * 256 * 64 + ((8 - 1) * ST + R) * ((32 - 1) * ST + R + (((32 - 1) * ST + R) & 1) + 2) * 8;
 }
 template <typename K> static int thin_lds_attr(K kern, int bytes) {
   VG_HIP(vg_lds_attr((const void*)kern, bytes));
@@ -679,7 +683,7 @@ extern "C" int vg_thin_conv_dgrad(const vg_conv_desc* d, const void* dy, const f
   return VG_OK;
 }
 
-static int thin_wgrad_blocks(const ThinParams& p) { return p.ntiles < 512 ? p.ntiles : 512; }
+static int thin_wgrad_blocks(const ThinParams& p) { return p.ntiles < 512 ? p.ntiles : 512; }      // (768 / 1024: no faster)
 
 extern "C" size_t vg_thin_conv_wgrad_ws_bytes(const vg_conv_desc* d) {
   const int kind = vg_thin_conv_supported(d);
