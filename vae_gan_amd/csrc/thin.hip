@@ -470,7 +470,6 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int mblk = wave >> 1, nblk = wave & 1;
-  const int py = tid >> 5, px = tid & 31;
   // transposed-read lane terms: lane (tq, tp) of the 16-lane group (h, g16) addresses pixel 8h + tq of the K step.
   // A: channels 16*g16 + 4*tp .. + 3 of its 32-channel image.  B: the 8-byte pixel that tap (r, s) = (2*nblk + g16, tp)
   // shifts to (columns 16*g16 + 4*tp .. + 3 of the block = that tap's four channels); taps beyond R x R address the
@@ -496,14 +495,15 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p) {
       if (idx < HH * HWP && (unsigned)iy < (unsigned)p.TH_ && (unsigned)ix < (unsigned)p.TW_) v = tg[((size_t)img * p.TH_ + iy) * p.TW_ + ix];
       nh_[u] = v;
     }
-    const int qy = ty0 + py, qx = tx0 + px;
-    const bool ok = qy < p.WH && qx < p.WW;
-    const bf16_t* src = p.wide + (((size_t)img * p.WH + qy) * p.WW + qx) * p.Ws;
+    // wide tile: load j of thread tid is 16-byte piece (j * 256 + tid) % 8 of pixel (j * 256 + tid) / 8: the 64 lanes of
+    // a load read 1 KB of consecutive memory (a pixel per thread made every load touch 64 lines for 16 bytes each)
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) {
+    for (int j = 0; j < 8; ++j) {
+      const int g = j * 256 + tid, pix = g >> 3, pc = g & 7;
+      const int qy = ty0 + (pix >> 5), qx = tx0 + (pix & 31);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok && pc * 8 < p.Ws) v = *(const u32x4*)(src + pc * 8);
-      nw_[pc] = v;
+      if (qy < p.WH && qx < p.WW && pc * 8 < p.Ws) v = *(const u32x4*)(p.wide + (((size_t)img * p.WH + qy) * p.WW + qx) * p.Ws + pc * 8);
+      nw_[j] = v;
     }
   };
   int tile = blockIdx.x;
@@ -514,7 +514,10 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p) {
     for (int u = 0; u < NH; ++u)
       if (tid + 256 * u < HH * HWP) halo[tid + 256 * u] = nh_[u];
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) *(u32x4*)(wI + (pc >> 2) * (256 * 64) + tid * 64 + (pc & 3) * 16) = nw_[pc];
+    for (int j = 0; j < 8; ++j) {
+      const int g = j * 256 + tid, pix = g >> 3, pc = g & 7;
+      *(u32x4*)(wI + (pc >> 2) * (256 * 64) + pix * 64 + (pc & 3) * 16) = nw_[j];
+    }
     if (tile + (int)gridDim.x < p.ntiles) request(tile + gridDim.x);
     __syncthreads();
     const unsigned char* hb = (const unsigned char*)halo;
